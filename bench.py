@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X-native stereo -> 8-view hot path.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
+
+A step = one synthetic 1080p side-by-side frame per rank through the device-resident frame pipeline
+(stm_d_adcensus_stm: cost init -> cross aggregation -> WTA -> DCC / IRV x5 / bilateral -> 6 DIBR views ->
+interlacing).  Inputs are resident in HBM before the timed region.  Frames are independent, so ranks share no
+data-path collective (scaling = weak); the only communication is the RCCL broadcast of the input batch from
+rank 0 before timing starts.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured with a float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--disp", type=int, default=64)
+    ap.add_argument("--stages", type=int, default=3, help="1 = cost+agg+WTA (config 2), 2 = +refinement (config 3), 3 = full frame")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--agg-variant", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(sbs, p, H, W, D, zd):
+    """The oracle (CPU restatement of the reference, kind 'port') timed on the host cores on a bounded sample:
+    the full pipeline on the top quarter-height strip of the same frame, scaled to whole frames."""
+    from oracle import pyoracle as orc
+    orc.build()
+    strip_h = max(H // 4, 64)
+    strip = np.ascontiguousarray(sbs[:strip_h])
+    t0 = time.perf_counter()
+    orc.adcensus_stm(strip, strip_h, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd, p.usd,
+                     p.lsd, p.thresh_s, p.thresh_h)
+    dt = time.perf_counter() - t0
+    fps = (1.0 / dt) * (strip_h / float(H))
+    return {"value": fps, "unit": "frames/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": "full pipeline (oracle/stm_oracle.c, OpenMP) on the top %dx%d strip of the same frame, D=%d, %.1f s; "
+                      "scaled by %d/%d to whole frames" % (W, strip_h, D, dt, strip_h, H)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import stm_amd
+    from stm_amd import device_api as dev, sharding, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    stm_amd.lib()  # raises if the HIP library is missing: there is no fallback path
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    H, W, D = args.height, args.width, args.disp
+    zd = D // 2
+    p = dev.FrameParams(num_disp=D, zero_disp=zd)  # SURVEY 8d defaults: usd=34, lsd=17, 8 views, angle 18.43
+    stm_amd.lib().stm_set_agg_variant(args.agg_variant)
+
+    # ---- input batch: one frame per rank, generated on rank 0, broadcast over RCCL (xGMI) -------------
+    batch = torch.zeros(world, H, 2 * W, 3, dtype=torch.uint8, device="cuda")
+    sbs_host = None
+    if rank == 0:
+        frames = []
+        for r in range(world):
+            f, _ = synth.sbs_frame(H, W, D, zd, seed=synth.SEED + r)
+            frames.append(f)
+        sbs_host = frames[0]
+        batch.copy_(torch.from_numpy(np.stack(frames)))
+    sharding.broadcast_batch(batch, src=0)
+    mine = sharding.shard_indices(world, rank, world)  # one frame per rank
+    frame = batch[mine[0]].contiguous()
+
+    dl = torch.zeros(H, W, dtype=torch.float32, device="cuda")
+    dr = torch.zeros_like(dl)
+    out = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+
+    def step():
+        dev.d_adcensus_stm(frame, dl, dr, out, p, stages=args.stages)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    dev.prof_reset()
+    dev.prof_enable(True)  # HIP events around the named kernels, on the launch stream, inside the timed region
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    dev.prof_enable(False)
+
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        V = float(D) * H * W * 4
+        HW = float(H) * W
+        # algorithmic bytes per launch: one un-fused pass over one view = 2V + 2HW;
+        # last pass fused with WTA = V + 2HW (arms) + 4HW (disparity out)
+        alg = {"agg_h": 2 * V + 2 * HW, "agg_v": 2 * V + 2 * HW, "agg_hw": V + 2 * HW + 4 * HW,
+               "cost_init": 2 * V + 4 * 4 * HW}
+        kern = {}
+        for name in ["agg_h", "agg_v", "agg_hw", "cost_init", "cross_arms", "irv_vote", "bilateral", "gaussian_max",
+                     "view_synth", "mux"]:
+            n, ms = dev.prof_read(name)
+            if n:
+                kern[name] = {"launches": n, "avg_ms": ms / n, "total_ms": ms}
+        dom = max([k for k in ("agg_h", "agg_v", "agg_hw") if k in kern], key=lambda k: kern[k]["total_ms"])
+        achieved = alg[dom] / (kern[dom]["avg_ms"] * 1e-3) / 1e9
+        agg_total_ms = sum(kern[k]["total_ms"] for k in ("agg_h", "agg_v", "agg_hw") if k in kern) / args.steps
+        agg_bytes = sum(alg[k] * kern[k]["launches"] for k in ("agg_h", "agg_v", "agg_hw") if k in kern) / args.steps
+        roofline = {"bound": "hbm", "kernel": "stm_k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern[dom]["avg_ms"],
+                    "agg_stage_ms_per_frame": agg_total_ms, "agg_stage_GBps": agg_bytes / (agg_total_ms * 1e-3) / 1e9}
+        fps = world * args.steps / dt
+        res = {
+            "metric": "stereo->8-view frames/sec @1080p d=64; cost-agg HBM GB/s vs roofline",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%dx%d synthetic stereo frame, D=%d, zd=%d, %s, one frame per GPU per step" % (
+                W, H, D, zd, {1: "cost init + cross aggregation + WTA (BASELINE config 2)",
+                              2: "config 2 + DCC + IRV x5 + bilateral (config 3)",
+                              3: "full stereo->8-view frame: cost init + cross aggregation + WTA + DCC/IRV x5/bilateral + 6 DIBR views + interlacing"}[args.stages]),
+                       "stages": args.stages, "usd": p.usd, "lsd": p.lsd, "views": p.num_views, "sharding": "frames, 1 per rank"},
+            "roofline": roofline,
+            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(sbs_host, p, H, W, D, zd)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

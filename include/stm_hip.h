@@ -1,0 +1,193 @@
+/*
+ * stm_hip.h -- C ABI of the MI355X-native stereo->multiview hot path (libstm_hip.so).
+ *
+ * Every entry point below replaces one function of the reference's per-stage host
+ * API.  The reference relies on C++ name mangling and has no
+ * C ABI, so each function is exported here as  stm_<reference name>  with the
+ * reference's argument list unchanged (same order, same meaning, same ownership):
+ *   - "host flavour"   stm_xxx   : every pointer is a HOST pointer; the call uploads,
+ *                                   runs the HIP kernels, downloads and returns only
+ *                                   when the outputs are visible to the host.
+ *   - "device flavour" stm_d_xxx : every pointer is a DEVICE pointer (plus the host
+ *                                   mirror tables the reference also passes); kernels
+ *                                   are enqueued on the current stream (stm_set_stream),
+ *                                   nothing is synchronised.
+ * C++ callers that want the reference's exact (mangled) names -- image_io.cpp /
+ * d_io.cu style call sites -- include stm_dropin.hpp instead.
+ *
+ * Layouts (reference: image_io.cpp:155-189, d_io.cu:71-101):
+ *   images      interleaved BGR u8, row-major, no row padding, elem_sz == 3
+ *   cost volume table of num_disp pointers, each a dense num_rows*num_cols float plane
+ *   cross arms  table of 4 pointers to u8 planes, order UP, DOWN, LEFT, RIGHT
+ *   disparity   float [H][W], signed offset (d - zero_disp)
+ *
+ * Errors: like the reference (cuda_utils.h:12-21) a HIP failure prints a message and
+ * calls exit(1); unlike it, kernel launches are checked too.  stm_set_error_mode(1)
+ * turns that into "record and return" for embedding hosts (query stm_last_error()).
+ *
+ * All file:line citations are relative to the reference repository root.
+ */
+#ifndef STM_HIP_H
+#define STM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(STM_BUILD) && defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+/* ---------------------------------------------------------------- runtime */
+int         stm_version(void);
+/* current HIP stream (a hipStream_t) used by every device-flavour call of this thread */
+void        stm_set_stream(void *hip_stream);
+void       *stm_get_stream(void);
+/* 0 = print + exit(1) like cuda_utils.h:12-21 (default); 1 = record, return, keep going */
+void        stm_set_error_mode(int mode);
+const char *stm_last_error(void);
+/* frees the cached device workspace (the reference cudaMalloc/cudaFree's per call) */
+void        stm_release_workspace(void);
+/* per-kernel HIP-event profiling of the dominant kernels inside the frame pipeline */
+void        stm_prof_enable(int on);
+void        stm_prof_reset(void);
+/* returns number of timed launches of `kernel` ("agg_h","agg_v","cost_init","agg_hw", ...) and their
+ * summed duration in ms; synchronises the recorded events. */
+int         stm_prof_read(const char *kernel, float *total_ms);
+/* aggregation kernel variant (0 = default); used by the benchmark to A/B variants in one process */
+void        stm_set_agg_variant(int v);
+
+/* ------------------------------------------------------- cost init (a1-a7) */
+/* d_ci_adcensus.h:23-25  ci_adcensus  (d_ci_adcensus.cu:188-378) */
+void stm_ci_adcensus(unsigned char *img_l, unsigned char *img_r, float **cost_l, float **cost_r,
+                     float ad_coeff, float census_coeff, int num_disp, int zero_disp,
+                     int num_rows, int num_cols, int elem_sz);
+/* d_ci_adcensus.h:16-21  d_ci_adcensus (d_ci_adcensus.cu:38-186).  Fills the host and device plane
+ * tables exactly as :150-157 does: L plane d at memory + d*H*W, R plane d at memory + (D + d)*H*W. */
+void stm_d_ci_adcensus(unsigned char *d_img_l, unsigned char *d_img_r,
+                       float **d_adcensus_cost_l, float **d_adcensus_cost_r,
+                       float **h_adcensus_cost_l, float **h_adcensus_cost_r,
+                       float *d_adcensus_cost_memory,
+                       float ad_coeff, float census_coeff, int num_disp, int zero_disp,
+                       int num_rows, int num_cols, int elem_sz);
+
+/* ------------------------------------------------ cross aggregation (a8-a12) */
+/* d_ca_cross.h:19-21  ca_cross (d_ca_cross.cu:275-444): cost untouched, result in acost, arms in cross */
+void stm_ca_cross(unsigned char *img, unsigned char **cross, float **cost, float **acost,
+                  float ucd, float lcd, int usd, int lsd,
+                  int num_disp, int num_rows, int num_cols, int elem_sz);
+/* d_ca_cross.h:13-17  d_ca_cross (d_ca_cross.cu:174-273): RESULT LANDS IN d_cost (input overwritten),
+ * d_acost/d_acost_memory are scratch; h_acost and d_acost tables are filled as :207-210 does. */
+void stm_d_ca_cross(unsigned char *d_img, float **d_cost,
+                    float **d_acost, float **h_acost, float *d_acost_memory,
+                    unsigned char **d_cross,
+                    float ucd, float lcd, int usd, int lsd,
+                    int num_disp, int num_rows, int num_cols, int elem_sz);
+
+/* ------------------------------------------------- disparity selection (a13,a14) */
+/* d_dc_wta.h:16-18 / :12-14  (d_dc_wta.cu:9-59) */
+void stm_dc_wta(float **cost, float *disp, int num_disp, int zero_disp, int num_rows, int num_cols);
+void stm_d_dc_wta(float **d_cost, float *d_disp, int num_disp, int zero_disp, int num_rows, int num_cols);
+/* d_dc_hslo.h:18-22  dc_hslo (d_dc_hslo.cu:97-221, a stub in the reference; implemented here, parity unpinned) */
+void stm_dc_hslo(float **cost, float *disp, unsigned char *img_l, unsigned char *img_r,
+                 float T, float H1, float H2, int num_disp, int zero_disp,
+                 int num_rows, int num_cols, int elem_sz);
+/* device flavour: the reference has none; same contract as the other d_ calls */
+void stm_d_dc_hslo(float **d_cost, float *d_disp, unsigned char *d_img_l, unsigned char *d_img_r,
+                   float T, float H1, float H2, int num_disp, int zero_disp,
+                   int num_rows, int num_cols, int elem_sz);
+
+/* -------------------------------------------------------- refinement (a15-a17) */
+/* d_dr_dcc.h:17-19 / :13-15  (d_dr_dcc.cu:84-203).  Host flavour zero-fills the outlier maps itself
+ * (:166-171); the device flavour expects them zero-filled by the caller (d_io.cu:138-141). */
+void stm_dr_dcc(unsigned char *outliers_l, unsigned char *outliers_r, float *disp_l, float *disp_r,
+                int num_rows, int num_cols);
+void stm_d_dr_dcc(unsigned char *d_outliers_l, unsigned char *d_outliers_r, float *d_disp_l, float *d_disp_r,
+                  int num_rows, int num_cols);
+/* d_dr_irv.h:15-19 / :8-13  (d_dr_irv.cu:222-364).  Host flavour votes once and applies `iterations`
+ * times (:344-353); device flavour repeats vote+apply (:259-265). */
+void stm_dr_irv(float *disp, unsigned char *outliers, unsigned char **cross, int thresh_s, float thresh_h,
+                int num_rows, int num_cols, int num_disp, int zero_disp, int usd, int iterations);
+void stm_d_dr_irv(float *d_disp, unsigned char *d_outliers, unsigned char **d_cross, int thresh_s, float thresh_h,
+                  int num_rows, int num_cols, int num_disp, int zero_disp, int usd, int iterations);
+/* d_filter_bilateral.h:17-20 / :13-15  (d_filter_bilateral.cu:517-630) */
+void stm_filter_bilateral_1(float *img, int radius, float sigma_color, float sigma_spatial,
+                            int num_rows, int num_cols, int num_disp);
+void stm_d_filter_bilateral_1(float *d_img, int radius, float sigma_color, float sigma_spatial,
+                              int num_rows, int num_cols, int num_disp);
+/* d_filter_gaussian.h:20-26  (d_filter_gaussian.cu:134-234): grow-only gaussian, out = max(in, blur) */
+void stm_filter_gaussian_1(float *img, int radius, float sigma_spatial, int num_rows, int num_cols);
+void stm_d_filter_gaussian_1(float *d_img, int radius, float sigma_spatial, int num_rows, int num_cols);
+/* d_filter.h:22-28  (d_filter.cu:105-167 and following) */
+void stm_filter_bleed_1(unsigned char *img, int radius, int num_rows, int num_cols);
+void stm_d_filter_bleed_1(unsigned char *d_img, int radius, int num_rows, int num_cols);
+
+/* --------------------------------------------------------------- DIBR (a18-a23) */
+/* d_dibr_occl.h:27-33  (d_dibr_occl.cu:130-218) */
+void stm_dibr_occl(unsigned char *occl_l, unsigned char *occl_r, float *disp_l, float *disp_r,
+                   int num_rows, int num_cols);
+void stm_d_dibr_occl(unsigned char *d_occl_l, unsigned char *d_occl_r, float *d_disp_l, float *d_disp_r,
+                     int num_rows, int num_cols);
+/* d_dibr_occl.h:14-20  (d_dibr_occl.cu:17-112) */
+void stm_dibr_occl_to_mask(float *mask_l, float *mask_r, unsigned char *occl_l, unsigned char *occl_r,
+                           int num_rows, int num_cols);
+void stm_d_dibr_occl_to_mask(float *d_mask_l, float *d_mask_r, unsigned char *d_occl_l, unsigned char *d_occl_r,
+                             int num_rows, int num_cols);
+/* d_dibr_bwarp.h:22-34  (d_dibr_bwarp.cu:24-180).  Host flavour blurs the mask with gaussian(7,10)
+ * (:151), device flavour with gaussian(10,15) (:63).  Neither modifies the caller's masks. */
+void stm_dibr_dbm(unsigned char *img_out, unsigned char *img_in_l, unsigned char *img_in_r,
+                  float *disp_l, float *disp_r, unsigned char *occl_l, unsigned char *occl_r,
+                  float *mask_l, float *mask_r, float shift, int num_rows, int num_cols, int elem_sz);
+void stm_d_dibr_dbm(unsigned char *d_img_out, unsigned char *d_img_in_l, unsigned char *d_img_in_r,
+                    float *d_disp_l, float *d_disp_r, unsigned char *d_occl_l, unsigned char *d_occl_r,
+                    float *d_mask_l, float *d_mask_r, float shift, int num_rows, int num_cols, int elem_sz);
+/* d_dibr_fwarp.h:12-20  (d_dibr_fwarp.cu:27-193): racy in the reference; deterministic here
+ * (largest source x wins), parity unpinned */
+void stm_dibr_dfm(unsigned char *img_out, unsigned char *img_in_l, unsigned char *img_in_r,
+                  float *disp_l, float *disp_r, float shift, int num_rows, int num_cols, int elem_sz);
+void stm_d_dibr_dfm(unsigned char *d_img_out, unsigned char *d_img_in_l, unsigned char *d_img_in_r,
+                    float *d_disp_l, float *d_disp_r, float shift, int num_rows, int num_cols, int elem_sz);
+
+/* ---------------------------------------------------------------- mux (a24, a25) */
+/* d_mux_multiview.h:35-41  (d_mux_multiview.cu:126-220) */
+void stm_mux_multiview(unsigned char **views, unsigned char *out_data, int num_views, float angle,
+                       int in_rows, int in_cols, int out_rows, int out_cols, int elem_sz);
+void stm_d_mux_multiview(unsigned char **d_views, unsigned char *d_out_data, int num_views, float angle,
+                         int in_rows, int in_cols, int out_rows, int out_cols, int elem_sz);
+/* d_demux_common.h:10-13  demux_sbs kernel (d_demux_common.cu:8-33) as a host-callable stage */
+void stm_d_demux_sbs(unsigned char *d_img_l, unsigned char *d_img_r, unsigned char *d_img_sbs,
+                     int num_rows, int num_cols_sbs, int num_cols_out, int elem_sz);
+
+/* ------------------------------------------------------------ whole frame (a26) */
+/* d_io.h:32-40  adcensus_stm (d_io.cu:7-238).  `angle` is float here (the reference's int truncates
+ * the caller's float, SURVEY A-Q24). */
+void stm_adcensus_stm(unsigned char *img_sbs, float *disp_l, float *disp_r, unsigned char *interlaced,
+                      int num_rows, int num_cols_sbs, int num_cols,
+                      int num_rows_out, int num_cols_out, int elem_sz,
+                      int num_views, float angle, int num_disp, int zero_disp,
+                      float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
+                      int thresh_s, float thresh_h);
+/* Device-resident frame: same pipeline, all four buffers already in HBM, nothing synchronised.
+ * stages: 1 = cost init + aggregation + WTA only (BASELINE config 2);
+ *         2 = + DCC / IRV x5 / bilateral          (config 3);
+ *         3 = + DIBR views + interlacing           (config 4, the full adcensus_stm). */
+void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp_r, unsigned char *d_interlaced,
+                        int num_rows, int num_cols_sbs, int num_cols,
+                        int num_rows_out, int num_cols_out, int elem_sz,
+                        int num_views, float angle, int num_disp, int zero_disp,
+                        float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
+                        int thresh_s, float thresh_h, int stages);
+
+/* ----------------------------------------------------------------- BMP I/O */
+/* image_io.cpp:95-112 reads the pair with cv::imread; these read/write the same 24-bit BMPs.
+ * stm_bmp_read returns a malloc'd BGR buffer (free with stm_bmp_free) or NULL. */
+unsigned char *stm_bmp_read(const char *path, int *num_rows, int *num_cols);
+int            stm_bmp_write(const char *path, const unsigned char *bgr, int num_rows, int num_cols);
+void           stm_bmp_free(unsigned char *p);
+
+#if defined(STM_BUILD) && defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* STM_HIP_H */

@@ -1,0 +1,567 @@
+// stm_api.hip -- the C ABI (include/stm_hip.h): host-flavour and device-flavour stage entry points
+// and the device-resident frame pipeline.  Mirrors the reference's per-stage host API
+// (SURVEY.md section 8b); each function cites the reference wrapper it replaces.
+#include "stm_common.h"
+#include "../../include/stm_hip.h"
+
+#include <map>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <tuple>
+#include <vector>
+
+using namespace stm;
+
+namespace {
+
+// ---------------------------------------------------------------- small persistent device tables
+struct DevTable {
+    float *d = nullptr;
+    size_t n = 0;
+};
+std::map<std::tuple<int, int, float, float>, DevTable> g_tables; // (dev*8+kind, size/radius, p0, p1)
+
+int cur_dev()
+{
+    int dev = 0;
+    STM_CHECK(hipGetDevice(&dev));
+    return dev;
+}
+
+const float *dev_table(int kind, int size, float p0, float p1, size_t n, void (*fill)(float *, int, float, float))
+{
+    auto key = std::make_tuple(cur_dev() * 8 + kind, size, p0, p1);
+    auto it = g_tables.find(key);
+    if (it != g_tables.end()) return it->second.d;
+    std::vector<float> h(n);
+    fill(h.data(), size, p0, p1);
+    DevTable t;
+    t.n = n;
+    STM_CHECK(hipMalloc((void **)&t.d, n * sizeof(float)));
+    STM_CHECK(hipMemcpy(t.d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    g_tables[key] = t;
+    return t.d;
+}
+void fill_rho(float *h, int, float ad, float ce) { rho_luts(ad, ce, h, h + 768); }
+void fill_g2(float *h, int r, float s, float) { gaussian_kernel_2d(h, r, s); }
+void fill_g1(float *h, int n, float s, float) { gaussian_kernel_1d(h, n, s); }
+
+const float *rho_table(float ad, float ce) { return dev_table(0, 0, ad, ce, 768 + 72, fill_rho); } // [0..765] ad, [768..832] census
+const float *gauss2d_table(int r, float s) { return dev_table(1, r, s, 0.f, (size_t)(2 * r + 1) * (2 * r + 1), fill_g2); }
+const float *gauss1d_table(int n, float s) { return dev_table(2, n, s, 0.f, (size_t)(n > 0 ? n : 1), fill_g1); }
+
+void sync() { STM_CHECK(hipStreamSynchronize(stream())); }
+
+template <class T> T *up(const T *h, size_t n)
+{
+    T *d = Workspace::get<T>(n);
+    STM_CHECK(hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, stream()));
+    return d;
+}
+template <class T> void down(T *h, const T *d, size_t n)
+{
+    STM_CHECK(hipMemcpyAsync(h, d, n * sizeof(T), hipMemcpyDeviceToHost, stream()));
+}
+float *up_planes(float **planes, int D, size_t HW)
+{
+    float *slab = Workspace::get<float>((size_t)D * HW);
+    for (int d = 0; d < D; ++d)
+        STM_CHECK(hipMemcpyAsync(slab + (size_t)d * HW, planes[d], HW * sizeof(float), hipMemcpyHostToDevice, stream()));
+    return slab;
+}
+void down_planes(float **planes, const float *slab, int D, size_t HW)
+{
+    for (int d = 0; d < D; ++d)
+        STM_CHECK(hipMemcpyAsync(planes[d], slab + (size_t)d * HW, HW * sizeof(float), hipMemcpyDeviceToHost, stream()));
+}
+
+struct Arms {
+    u8 *up, *down, *left, *right;
+};
+
+// ---------------------------------------------------------------- device cores
+// cost init: pack -> census -> fused AD + census + robust combine
+void core_ci(const u8 *d_img_l, const u8 *d_img_r, Vol cl, Vol cr, uint32_t *pk_l, uint32_t *pk_r, float ad_coeff,
+             float census_coeff, int D, int zd, int H, int W, int elem_sz)
+{
+    size_t HW = (size_t)H * W;
+    uint32_t *cen_l = Workspace::get<uint32_t>(HW), *cen_r = Workspace::get<uint32_t>(HW);
+    launch_pack_bgrx(d_img_l, pk_l, H, W, elem_sz);
+    launch_pack_bgrx(d_img_r, pk_r, H, W, elem_sz);
+    launch_census32(pk_l, cen_l, H, W);
+    launch_census32(pk_r, cen_r, H, W);
+    const float *lut = rho_table(ad_coeff, census_coeff);
+    launch_cost_init(pk_l, pk_r, cen_l, cen_r, cl, cr, lut, lut + 768, D, zd, H, W);
+}
+
+// aggregation H, V, V, H (d_ca_cross.cu:255-270 minus the transposes); result ends in `cost`
+void core_agg(Vol cost, Vol scratch, const Arms &a, int D, int H, int W, int usd)
+{
+    launch_agg_h(cost, scratch, a.left, a.right, D, H, W);
+    launch_agg_v(scratch, cost, a.up, a.down, D, H, W, usd);
+    launch_agg_v(cost, scratch, a.up, a.down, D, H, W, usd);
+    launch_agg_h(scratch, cost, a.left, a.right, D, H, W);
+}
+// same, but the last pass feeds WTA directly: `cost` ends up holding pass 2 (garbage for callers)
+void core_agg_wta(Vol cost, Vol scratch, const Arms &a, float *disp, int D, int zd, int H, int W, int usd)
+{
+    launch_agg_h(cost, scratch, a.left, a.right, D, H, W);
+    launch_agg_v(scratch, cost, a.up, a.down, D, H, W, usd);
+    launch_agg_v(cost, scratch, a.up, a.down, D, H, W, usd);
+    launch_agg_h_wta(scratch, a.left, a.right, disp, D, zd, H, W);
+}
+
+Arms carve_arms(size_t HW)
+{
+    u8 *m = Workspace::get<u8>(4 * HW);
+    return Arms{m, m + HW, m + 2 * HW, m + 3 * HW};
+}
+Arms arms_from_table(unsigned char **d_cross)
+{
+    // the reference hands the four plane pointers over as a DEVICE table (d_io.cu:94-101); fetch them
+    u8 *h[4];
+    STM_CHECK(hipMemcpyAsync(h, d_cross, sizeof h, hipMemcpyDeviceToHost, stream()));
+    sync();
+    return Arms{h[0], h[1], h[2], h[3]};
+}
+
+void core_bilateral(float *d_img, int radius, float sigma_color, float sigma_spatial, int H, int W, int D)
+{
+    size_t HW = (size_t)H * W;
+    float *tmp = Workspace::get<float>(HW);
+    launch_bilateral(d_img, tmp, gauss2d_table(radius, sigma_spatial), gauss1d_table(D, sigma_color), radius, H, W, D);
+    STM_CHECK(hipMemcpyAsync(d_img, tmp, HW * sizeof(float), hipMemcpyDeviceToDevice, stream())); // d_filter_bilateral.cu:560
+}
+
+void core_dbm(u8 *d_out, const u8 *d_l, const u8 *d_r, const float *disp_l, const float *disp_r, const float *mask_l,
+              const float *mask_r, float shift, int H, int W, int elem_sz, int g_radius, float g_sigma)
+{
+    size_t HW = (size_t)H * W;
+    float *blend = Workspace::get<float>(HW);
+    launch_gaussian_max(mask_r, blend, gauss2d_table(g_radius, g_sigma), g_radius, H, W, true); // G(1 - maskR)
+    launch_view_synth(d_out, d_l, d_r, disp_l, disp_r, mask_l, mask_r, blend, shift, H, W, elem_sz);
+}
+
+void core_mux(const u8 *const *d_views, u8 *d_out, int N, float angle, int Hin, int Win, int Hout, int Wout, int elem_sz,
+              int variant)
+{
+    float yi = mux_y_interval(N, angle, elem_sz);
+    int ymod = (int)roundf(yi);
+    if (ymod == 0) fail("mux_multiview: round(y_interval) == 0 (angle too steep)", "ymod", __FILE__, __LINE__);
+    launch_mux(d_views, d_out, N, yi, 1.0f / yi, ymod == 0 ? 1 : ymod, Hin, Win, Hout, Wout, elem_sz, variant);
+}
+
+} // namespace
+
+extern "C" {
+
+// =============================================================== cost init
+void stm_d_ci_adcensus(unsigned char *d_img_l, unsigned char *d_img_r, float **d_adcensus_cost_l,
+                       float **d_adcensus_cost_r, float **h_adcensus_cost_l, float **h_adcensus_cost_r,
+                       float *d_adcensus_cost_memory, float ad_coeff, float census_coeff, int num_disp, int zero_disp,
+                       int num_rows, int num_cols, int elem_sz)
+{
+    size_t HW = (size_t)num_rows * num_cols, V = HW * num_disp;
+    Workspace::begin(4 * HW * 4 + 4096);
+    for (int d = 0; d < num_disp; ++d) { // d_ci_adcensus.cu:150-157
+        h_adcensus_cost_l[d] = d_adcensus_cost_memory + (size_t)d * HW;
+        h_adcensus_cost_r[d] = d_adcensus_cost_memory + (size_t)d * HW + V;
+    }
+    STM_CHECK(hipMemcpyAsync(d_adcensus_cost_l, h_adcensus_cost_l, sizeof(float *) * num_disp, hipMemcpyHostToDevice, stream()));
+    STM_CHECK(hipMemcpyAsync(d_adcensus_cost_r, h_adcensus_cost_r, sizeof(float *) * num_disp, hipMemcpyHostToDevice, stream()));
+    uint32_t *pk_l = Workspace::get<uint32_t>(HW), *pk_r = Workspace::get<uint32_t>(HW);
+    core_ci(d_img_l, d_img_r, vol_slab(d_adcensus_cost_memory, HW), vol_slab(d_adcensus_cost_memory + V, HW), pk_l, pk_r,
+            ad_coeff, census_coeff, num_disp, zero_disp, num_rows, num_cols, elem_sz);
+}
+
+void stm_ci_adcensus(unsigned char *img_l, unsigned char *img_r, float **cost_l, float **cost_r, float ad_coeff,
+                     float census_coeff, int num_disp, int zero_disp, int num_rows, int num_cols, int elem_sz)
+{
+    size_t HW = (size_t)num_rows * num_cols, V = HW * num_disp;
+    Workspace::begin(2 * V * 4 + 2 * HW * elem_sz + 4 * HW * 4 + 8192);
+    u8 *dl = up(img_l, HW * elem_sz), *dr = up(img_r, HW * elem_sz);
+    float *slab = Workspace::get<float>(2 * V);
+    uint32_t *pk_l = Workspace::get<uint32_t>(HW), *pk_r = Workspace::get<uint32_t>(HW);
+    core_ci(dl, dr, vol_slab(slab, HW), vol_slab(slab + V, HW), pk_l, pk_r, ad_coeff, census_coeff, num_disp, zero_disp,
+            num_rows, num_cols, elem_sz);
+    down_planes(cost_l, slab, num_disp, HW);
+    down_planes(cost_r, slab + V, num_disp, HW);
+    sync();
+}
+
+// =============================================================== aggregation
+void stm_d_ca_cross(unsigned char *d_img, float **d_cost, float **d_acost, float **h_acost, float *d_acost_memory,
+                    unsigned char **d_cross, float ucd, float lcd, int usd, int lsd, int num_disp, int num_rows,
+                    int num_cols, int elem_sz)
+{
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(HW * 4 + 4096);
+    for (int d = 0; d < num_disp; ++d) h_acost[d] = d_acost_memory + (size_t)d * HW; // d_ca_cross.cu:207-210
+    STM_CHECK(hipMemcpyAsync(d_acost, h_acost, sizeof(float *) * num_disp, hipMemcpyHostToDevice, stream()));
+    Arms a = arms_from_table(d_cross);
+    uint32_t *pk = Workspace::get<uint32_t>(HW);
+    launch_pack_bgrx(d_img, pk, num_rows, num_cols, elem_sz);
+    launch_cross_arms(pk, a.up, a.down, a.left, a.right, ucd, lcd, usd, lsd, num_rows, num_cols);
+    core_agg(vol_table(d_cost), vol_slab(d_acost_memory, HW), a, num_disp, num_rows, num_cols, usd); // result in d_cost (A-Q11)
+}
+
+void stm_ca_cross(unsigned char *img, unsigned char **cross, float **cost, float **acost, float ucd, float lcd, int usd,
+                  int lsd, int num_disp, int num_rows, int num_cols, int elem_sz)
+{
+    size_t HW = (size_t)num_rows * num_cols, V = HW * num_disp;
+    Workspace::begin(2 * V * 4 + HW * elem_sz + 8 * HW + 8192);
+    u8 *dimg = up(img, HW * elem_sz);
+    float *c = up_planes(cost, num_disp, HW);
+    float *s = Workspace::get<float>(V);
+    Arms a = carve_arms(HW);
+    uint32_t *pk = Workspace::get<uint32_t>(HW);
+    launch_pack_bgrx(dimg, pk, num_rows, num_cols, elem_sz);
+    launch_cross_arms(pk, a.up, a.down, a.left, a.right, ucd, lcd, usd, lsd, num_rows, num_cols);
+    core_agg(vol_slab(c, HW), vol_slab(s, HW), a, num_disp, num_rows, num_cols, usd);
+    down_planes(acost, c, num_disp, HW); // d_ca_cross.cu:419-422: the "cost" device buffer goes to acost
+    down(cross[0], a.up, HW); down(cross[1], a.down, HW); down(cross[2], a.left, HW); down(cross[3], a.right, HW);
+    sync();
+}
+
+// =============================================================== disparity selection
+void stm_d_dc_wta(float **d_cost, float *d_disp, int num_disp, int zero_disp, int num_rows, int num_cols)
+{
+    launch_wta(vol_table(d_cost), d_disp, num_disp, zero_disp, num_rows, num_cols);
+}
+void stm_dc_wta(float **cost, float *disp, int num_disp, int zero_disp, int num_rows, int num_cols)
+{
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin((size_t)num_disp * HW * 4 + HW * 4 + 4096);
+    float *c = up_planes(cost, num_disp, HW);
+    float *d = Workspace::get<float>(HW);
+    launch_wta(vol_slab(c, HW), d, num_disp, zero_disp, num_rows, num_cols);
+    down(disp, d, HW);
+    sync();
+}
+
+void stm_d_dc_hslo(float **d_cost, float *d_disp, unsigned char *d_img_l, unsigned char *d_img_r, float T, float H1,
+                   float H2, int num_disp, int zero_disp, int num_rows, int num_cols, int elem_sz)
+{
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin((size_t)num_disp * HW * 4 + 4096);
+    float *acc = Workspace::get<float>((size_t)num_disp * HW);
+    Vol a = vol_slab(acc, HW);
+    launch_hslo(vol_table(d_cost), a, d_img_l, d_img_r, T, H1, H2, num_disp, zero_disp, num_rows, num_cols, elem_sz);
+    launch_scale_volume(a, 0.25f, num_disp, num_rows, num_cols);
+    launch_wta(a, d_disp, num_disp, zero_disp, num_rows, num_cols);
+}
+void stm_dc_hslo(float **cost, float *disp, unsigned char *img_l, unsigned char *img_r, float T, float H1, float H2,
+                 int num_disp, int zero_disp, int num_rows, int num_cols, int elem_sz)
+{
+    size_t HW = (size_t)num_rows * num_cols, V = HW * num_disp;
+    Workspace::begin(2 * V * 4 + 2 * HW * elem_sz + HW * 4 + 8192);
+    float *c = up_planes(cost, num_disp, HW);
+    u8 *dl = up(img_l, HW * elem_sz), *dr = up(img_r, HW * elem_sz);
+    float *acc = Workspace::get<float>(V), *d = Workspace::get<float>(HW);
+    Vol a = vol_slab(acc, HW);
+    launch_hslo(vol_slab(c, HW), a, dl, dr, T, H1, H2, num_disp, zero_disp, num_rows, num_cols, elem_sz);
+    launch_scale_volume(a, 0.25f, num_disp, num_rows, num_cols);
+    launch_wta(a, d, num_disp, zero_disp, num_rows, num_cols);
+    down(disp, d, HW);
+    sync();
+}
+
+// =============================================================== refinement
+void stm_d_dr_dcc(unsigned char *d_outliers_l, unsigned char *d_outliers_r, float *d_disp_l, float *d_disp_r, int num_rows,
+                  int num_cols)
+{
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(2 * HW + 1024);
+    u8 *hl = Workspace::get<u8>(HW), *hr = Workspace::get<u8>(HW);
+    launch_dcc(d_outliers_l, d_outliers_r, d_disp_l, d_disp_r, hl, hr, num_rows, num_cols);
+}
+void stm_dr_dcc(unsigned char *outliers_l, unsigned char *outliers_r, float *disp_l, float *disp_r, int num_rows,
+                int num_cols)
+{
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(12 * HW + 4096);
+    float *dl = up(disp_l, HW), *dr = up(disp_r, HW);
+    u8 *ol = Workspace::get<u8>(HW), *orr = Workspace::get<u8>(HW), *hl = Workspace::get<u8>(HW), *hr = Workspace::get<u8>(HW);
+    STM_CHECK(hipMemsetAsync(ol, 0, HW, stream())); // d_dr_dcc.cu:166-171
+    STM_CHECK(hipMemsetAsync(orr, 0, HW, stream()));
+    launch_dcc(ol, orr, dl, dr, hl, hr, num_rows, num_cols);
+    down(outliers_l, ol, HW); down(outliers_r, orr, HW);
+    sync();
+}
+
+void stm_d_dr_irv(float *d_disp, unsigned char *d_outliers, unsigned char **d_cross, int thresh_s, float thresh_h,
+                  int num_rows, int num_cols, int num_disp, int zero_disp, int usd, int iterations)
+{
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(8 * HW + 1024);
+    Arms a = arms_from_table(d_cross);
+    int *md = Workspace::get<int>(HW), *rel = Workspace::get<int>(HW);
+    launch_irv(d_disp, d_outliers, a.up, a.down, a.left, a.right, md, rel, thresh_s, thresh_h, num_rows, num_cols, num_disp,
+               zero_disp, usd, iterations, true);
+}
+void stm_dr_irv(float *disp, unsigned char *outliers, unsigned char **cross, int thresh_s, float thresh_h, int num_rows,
+                int num_cols, int num_disp, int zero_disp, int usd, int iterations)
+{
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(20 * HW + 8192);
+    float *d = up(disp, HW);
+    u8 *o = up(outliers, HW);
+    Arms a{up(cross[0], HW), up(cross[1], HW), up(cross[2], HW), up(cross[3], HW)};
+    int *md = Workspace::get<int>(HW), *rel = Workspace::get<int>(HW);
+    launch_irv(d, o, a.up, a.down, a.left, a.right, md, rel, thresh_s, thresh_h, num_rows, num_cols, num_disp, zero_disp, usd,
+               iterations, false);
+    down(disp, d, HW); down(outliers, o, HW);
+    sync();
+}
+
+void stm_d_filter_bilateral_1(float *d_img, int radius, float sigma_color, float sigma_spatial, int num_rows, int num_cols,
+                              int num_disp)
+{
+    Workspace::begin((size_t)num_rows * num_cols * 4 + 1024);
+    core_bilateral(d_img, radius, sigma_color, sigma_spatial, num_rows, num_cols, num_disp);
+}
+void stm_filter_bilateral_1(float *img, int radius, float sigma_color, float sigma_spatial, int num_rows, int num_cols,
+                            int num_disp)
+{
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(8 * HW + 4096);
+    float *d = up(img, HW);
+    core_bilateral(d, radius, sigma_color, sigma_spatial, num_rows, num_cols, num_disp);
+    down(img, d, HW);
+    sync();
+}
+
+void stm_d_filter_gaussian_1(float *d_img, int radius, float sigma_spatial, int num_rows, int num_cols)
+{
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(HW * 4 + 1024);
+    float *tmp = Workspace::get<float>(HW);
+    launch_gaussian_max(d_img, tmp, gauss2d_table(radius, sigma_spatial), radius, num_rows, num_cols, false);
+    STM_CHECK(hipMemcpyAsync(d_img, tmp, HW * 4, hipMemcpyDeviceToDevice, stream())); // d_filter_gaussian.cu:171
+}
+void stm_filter_gaussian_1(float *img, int radius, float sigma_spatial, int num_rows, int num_cols)
+{
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(8 * HW + 4096);
+    float *d = up(img, HW), *tmp = Workspace::get<float>(HW);
+    launch_gaussian_max(d, tmp, gauss2d_table(radius, sigma_spatial), radius, num_rows, num_cols, false);
+    down(img, tmp, HW);
+    sync();
+}
+
+void stm_d_filter_bleed_1(unsigned char *d_img, int radius, int num_rows, int num_cols)
+{
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(HW + 1024);
+    u8 *tmp = Workspace::get<u8>(HW);
+    launch_bleed(d_img, tmp, radius, num_rows, num_cols);
+    STM_CHECK(hipMemcpyAsync(d_img, tmp, HW, hipMemcpyDeviceToDevice, stream())); // d_filter.cu:164
+}
+void stm_filter_bleed_1(unsigned char *img, int radius, int num_rows, int num_cols)
+{
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(2 * HW + 4096);
+    u8 *d = up(img, HW), *tmp = Workspace::get<u8>(HW);
+    launch_bleed(d, tmp, radius, num_rows, num_cols);
+    down(img, tmp, HW);
+    sync();
+}
+
+// =============================================================== DIBR
+void stm_d_dibr_occl(unsigned char *d_occl_l, unsigned char *d_occl_r, float *d_disp_l, float *d_disp_r, int num_rows,
+                     int num_cols)
+{
+    launch_occl(d_occl_l, d_occl_r, d_disp_l, d_disp_r, num_rows, num_cols);
+}
+void stm_dibr_occl(unsigned char *occl_l, unsigned char *occl_r, float *disp_l, float *disp_r, int num_rows, int num_cols)
+{
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(10 * HW + 4096);
+    float *dl = up(disp_l, HW), *dr = up(disp_r, HW);
+    u8 *ol = Workspace::get<u8>(HW), *orr = Workspace::get<u8>(HW);
+    launch_occl(ol, orr, dl, dr, num_rows, num_cols);
+    down(occl_l, ol, HW); down(occl_r, orr, HW);
+    sync();
+}
+
+void stm_d_dibr_occl_to_mask(float *d_mask_l, float *d_mask_r, unsigned char *d_occl_l, unsigned char *d_occl_r,
+                             int num_rows, int num_cols)
+{
+    launch_occl_to_mask(d_mask_l, d_mask_r, d_occl_l, d_occl_r, num_rows, num_cols);
+}
+void stm_dibr_occl_to_mask(float *mask_l, float *mask_r, unsigned char *occl_l, unsigned char *occl_r, int num_rows,
+                           int num_cols)
+{
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(10 * HW + 4096);
+    u8 *ol = up(occl_l, HW), *orr = up(occl_r, HW);
+    float *ml = Workspace::get<float>(HW), *mr = Workspace::get<float>(HW);
+    launch_occl_to_mask(ml, mr, ol, orr, num_rows, num_cols);
+    down(mask_l, ml, HW); down(mask_r, mr, HW);
+    sync();
+}
+
+void stm_d_dibr_dbm(unsigned char *d_img_out, unsigned char *d_img_in_l, unsigned char *d_img_in_r, float *d_disp_l,
+                    float *d_disp_r, unsigned char *d_occl_l, unsigned char *d_occl_r, float *d_mask_l, float *d_mask_r,
+                    float shift, int num_rows, int num_cols, int elem_sz)
+{
+    (void)d_occl_l; (void)d_occl_r; // unused by the reference too (d_dibr_bwarp.cu:24-70)
+    Workspace::begin((size_t)num_rows * num_cols * 4 + 1024);
+    core_dbm(d_img_out, d_img_in_l, d_img_in_r, d_disp_l, d_disp_r, d_mask_l, d_mask_r, shift, num_rows, num_cols, elem_sz,
+             10, 15.0f); // d_dibr_bwarp.cu:63
+}
+void stm_dibr_dbm(unsigned char *img_out, unsigned char *img_in_l, unsigned char *img_in_r, float *disp_l, float *disp_r,
+                  unsigned char *occl_l, unsigned char *occl_r, float *mask_l, float *mask_r, float shift, int num_rows,
+                  int num_cols, int elem_sz)
+{
+    (void)occl_l; (void)occl_r;
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(3 * HW * elem_sz + 20 * HW + 8192);
+    u8 *l = up(img_in_l, HW * elem_sz), *r = up(img_in_r, HW * elem_sz), *o = Workspace::get<u8>(HW * elem_sz);
+    float *dl = up(disp_l, HW), *dr = up(disp_r, HW), *ml = up(mask_l, HW), *mr = up(mask_r, HW);
+    core_dbm(o, l, r, dl, dr, ml, mr, shift, num_rows, num_cols, elem_sz, 7, 10.0f); // d_dibr_bwarp.cu:151
+    down(img_out, o, HW * elem_sz);
+    sync();
+}
+
+void stm_d_dibr_dfm(unsigned char *d_img_out, unsigned char *d_img_in_l, unsigned char *d_img_in_r, float *d_disp_l,
+                    float *d_disp_r, float shift, int num_rows, int num_cols, int elem_sz)
+{
+    (void)d_img_in_r; (void)d_disp_r; // the right warp is computed and discarded in the reference (A-Q23)
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(HW * 8 + 1024);
+    unsigned long long *keys = Workspace::get<unsigned long long>(HW);
+    launch_fwarp(d_img_out, d_img_in_l, d_disp_l, shift, keys, num_rows, num_cols, elem_sz);
+}
+void stm_dibr_dfm(unsigned char *img_out, unsigned char *img_in_l, unsigned char *img_in_r, float *disp_l, float *disp_r,
+                  float shift, int num_rows, int num_cols, int elem_sz)
+{
+    (void)img_in_r; (void)disp_r;
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(2 * HW * elem_sz + 12 * HW + 8192);
+    u8 *l = up(img_in_l, HW * elem_sz), *o = Workspace::get<u8>(HW * elem_sz);
+    float *dl = up(disp_l, HW);
+    unsigned long long *keys = Workspace::get<unsigned long long>(HW);
+    launch_fwarp(o, l, dl, shift, keys, num_rows, num_cols, elem_sz);
+    down(img_out, o, HW * elem_sz);
+    sync();
+}
+
+// =============================================================== mux
+void stm_d_mux_multiview(unsigned char **d_views, unsigned char *d_out_data, int num_views, float angle, int in_rows,
+                         int in_cols, int out_rows, int out_cols, int elem_sz)
+{
+    core_mux((const u8 *const *)d_views, d_out_data, num_views, angle, in_rows, in_cols, out_rows, out_cols, elem_sz, 2); // :148-151
+}
+void stm_mux_multiview(unsigned char **views, unsigned char *out_data, int num_views, float angle, int in_rows, int in_cols,
+                       int out_rows, int out_cols, int elem_sz)
+{
+    size_t in_sz = (size_t)in_rows * in_cols * elem_sz, out_sz = (size_t)out_rows * out_cols * elem_sz;
+    Workspace::begin(num_views * (in_sz + 256) + out_sz + 8192);
+    std::vector<u8 *> h(num_views);
+    for (int v = 0; v < num_views; ++v) h[v] = up(views[v], in_sz);
+    u8 **dv = Workspace::get<u8 *>(num_views);
+    STM_CHECK(hipMemcpyAsync(dv, h.data(), sizeof(u8 *) * num_views, hipMemcpyHostToDevice, stream()));
+    sync(); // h goes out of scope below
+    u8 *o = Workspace::get<u8>(out_sz);
+    STM_CHECK(hipMemsetAsync(o, 0, out_sz, stream()));
+    int variant = (out_rows % num_views == 0) ? 2 : 1; // d_mux_multiview.cu:184-192
+    core_mux((const u8 *const *)dv, o, num_views, angle, in_rows, in_cols, out_rows, out_cols, elem_sz, variant);
+    down(out_data, o, out_sz);
+    sync();
+}
+
+void stm_d_demux_sbs(unsigned char *d_img_l, unsigned char *d_img_r, unsigned char *d_img_sbs, int num_rows,
+                     int num_cols_sbs, int num_cols_out, int elem_sz)
+{
+    launch_demux_sbs(d_img_l, d_img_r, d_img_sbs, num_rows, num_cols_sbs, num_cols_out, elem_sz);
+}
+
+// =============================================================== whole frame
+// adcensus_stm, d_io.cu:7-238: demux -> cost init -> aggregation (L, R) -> WTA -> DCC -> IRV x5 ->
+// bilateral(7,5,10) -> hit maps -> bleed(1) -> masks -> N-2 synthesised views -> interlace.
+// Differences in mechanics (not in results): one cached workspace instead of ~35 cudaMalloc/cudaFree,
+// no host synchronisation inside the frame, the last aggregation pass is fused with WTA, the mask
+// blur G(1 - maskR) is computed once per frame instead of once per view (it does not depend on the view).
+void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp_r, unsigned char *d_interlaced,
+                        int num_rows, int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out, int elem_sz,
+                        int num_views, float angle, int num_disp, int zero_disp, float ad_coeff, float census_coeff,
+                        float ucd, float lcd, int usd, int lsd, int thresh_s, float thresh_h, int stages)
+{
+    const int H = num_rows, W = num_cols, D = num_disp, N = num_views;
+    const size_t HW = (size_t)H * W, V = HW * D, IMG = HW * elem_sz;
+    Workspace::begin(3 * V * 4 + (size_t)(N + 2) * IMG + 64 * HW + (1u << 20));
+
+    u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
+    launch_demux_sbs(img_l, img_r, d_img_sbs, H, num_cols_sbs, W, elem_sz);
+
+    float *cost = Workspace::get<float>(2 * V), *scratch = Workspace::get<float>(V);
+    uint32_t *pk_l = Workspace::get<uint32_t>(HW), *pk_r = Workspace::get<uint32_t>(HW);
+    Vol cl = vol_slab(cost, HW), cr = vol_slab(cost + V, HW), sc = vol_slab(scratch, HW);
+    core_ci(img_l, img_r, cl, cr, pk_l, pk_r, ad_coeff, census_coeff, D, zero_disp, H, W, elem_sz);
+
+    Arms al = carve_arms(HW), ar = carve_arms(HW);
+    launch_cross_arms(pk_l, al.up, al.down, al.left, al.right, ucd, lcd, usd, lsd, H, W);
+    launch_cross_arms(pk_r, ar.up, ar.down, ar.left, ar.right, ucd, lcd, usd, lsd, H, W);
+    core_agg_wta(cl, sc, al, d_disp_l, D, zero_disp, H, W, usd);
+    core_agg_wta(cr, sc, ar, d_disp_r, D, zero_disp, H, W, usd);
+    if (stages < 2) return;
+
+    u8 *outl_l = Workspace::get<u8>(HW), *outl_r = Workspace::get<u8>(HW), *hit_l = Workspace::get<u8>(HW), *hit_r = Workspace::get<u8>(HW);
+    STM_CHECK(hipMemsetAsync(outl_l, 0, HW, stream())); // d_io.cu:138-141
+    STM_CHECK(hipMemsetAsync(outl_r, 0, HW, stream()));
+    launch_dcc(outl_l, outl_r, d_disp_l, d_disp_r, hit_l, hit_r, H, W);
+    int *md = Workspace::get<int>(HW), *rel = Workspace::get<int>(HW);
+    launch_irv(d_disp_l, outl_l, al.up, al.down, al.left, al.right, md, rel, thresh_s, thresh_h, H, W, D, zero_disp, usd, 5, true); // :147
+    launch_irv(d_disp_r, outl_r, ar.up, ar.down, ar.left, ar.right, md, rel, thresh_s, thresh_h, H, W, D, zero_disp, usd, 5, true); // :148
+    core_bilateral(d_disp_l, 7, 5.0f, 10.0f, H, W, D); // :150
+    core_bilateral(d_disp_r, 7, 5.0f, 10.0f, H, W, D); // :151
+    if (stages < 3) return;
+
+    u8 *occl_l = Workspace::get<u8>(HW), *occl_r = Workspace::get<u8>(HW), *tmp8 = Workspace::get<u8>(HW);
+    launch_occl(occl_l, occl_r, d_disp_l, d_disp_r, H, W); // :165
+    launch_bleed(occl_l, tmp8, 1, H, W);                   // :167
+    STM_CHECK(hipMemcpyAsync(occl_l, tmp8, HW, hipMemcpyDeviceToDevice, stream()));
+    launch_bleed(occl_r, tmp8, 1, H, W);                   // :168
+    STM_CHECK(hipMemcpyAsync(occl_r, tmp8, HW, hipMemcpyDeviceToDevice, stream()));
+    float *mask_l = Workspace::get<float>(HW), *mask_r = Workspace::get<float>(HW), *blend = Workspace::get<float>(HW);
+    launch_occl_to_mask(mask_l, mask_r, occl_l, occl_r, H, W); // :175-176
+    launch_gaussian_max(mask_r, blend, gauss2d_table(10, 15.0f), 10, H, W, true); // d_dibr_bwarp.cu:60-63, once per frame
+
+    u8 *views_mem = Workspace::get<u8>((size_t)N * IMG);
+    // views[0] = right image, views[N-1] = left image (d_io.cu:182-183)
+    for (int v = 1; v < N - 1; ++v) {
+        float shift = (float)(1.0 - ((1.0 * (double)(float)v) / ((double)(float)N - 1.0))); // :189
+        launch_view_synth(views_mem + (size_t)v * IMG, img_l, img_r, d_disp_l, d_disp_r, mask_l, mask_r, blend, shift, H, W, elem_sz);
+    }
+    // view table built on the device (no host memory involved, so nothing to keep alive or synchronise)
+    u8 **dv = Workspace::get<u8 *>(N);
+    launch_view_table(dv, img_r, img_l, views_mem, IMG, N);
+    core_mux((const u8 *const *)dv, d_interlaced, N, angle, H, W, num_rows_out, num_cols_out, elem_sz, 2); // :203
+}
+
+void stm_adcensus_stm(unsigned char *img_sbs, float *disp_l, float *disp_r, unsigned char *interlaced, int num_rows,
+                      int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out, int elem_sz, int num_views,
+                      float angle, int num_disp, int zero_disp, float ad_coeff, float census_coeff, float ucd, float lcd,
+                      int usd, int lsd, int thresh_s, float thresh_h)
+{
+    size_t HW = (size_t)num_rows * num_cols, sbs_sz = (size_t)num_rows * num_cols_sbs * elem_sz;
+    size_t out_sz = (size_t)num_rows_out * num_cols_out * elem_sz;
+    // own buffers come from plain hipMalloc: the pipeline call below re-carves the workspace
+    u8 *d_sbs, *d_out;
+    float *d_dl, *d_dr;
+    STM_CHECK(hipMalloc((void **)&d_sbs, sbs_sz));
+    STM_CHECK(hipMalloc((void **)&d_out, out_sz));
+    STM_CHECK(hipMalloc((void **)&d_dl, HW * 4));
+    STM_CHECK(hipMalloc((void **)&d_dr, HW * 4));
+    STM_CHECK(hipMemcpyAsync(d_sbs, img_sbs, sbs_sz, hipMemcpyHostToDevice, stream()));
+    STM_CHECK(hipMemsetAsync(d_out, 0, out_sz, stream()));
+    stm_d_adcensus_stm(d_sbs, d_dl, d_dr, d_out, num_rows, num_cols_sbs, num_cols, num_rows_out, num_cols_out, elem_sz,
+                       num_views, angle, num_disp, zero_disp, ad_coeff, census_coeff, ucd, lcd, usd, lsd, thresh_s, thresh_h, 3);
+    down(disp_l, d_dl, HW); down(disp_r, d_dr, HW); down(interlaced, d_out, out_sz);
+    sync();
+    STM_CHECK(hipFree(d_sbs)); STM_CHECK(hipFree(d_out)); STM_CHECK(hipFree(d_dl)); STM_CHECK(hipFree(d_dr));
+}
+
+} // extern "C"

@@ -1,0 +1,100 @@
+// stm_common.h -- internal runtime shared by the kernel files and the C-ABI layer.
+// gfx950 only.  Not installed; the public surface is include/stm_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+typedef unsigned char u8;
+
+namespace stm {
+
+// ---- error handling: reference semantics (cuda_utils.h:12-21) = message + exit(1) ----
+void fail(const char *what, const char *expr, const char *file, int line);
+#define STM_CHECK(expr)                                                                  \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) ::stm::fail(hipGetErrorString(_e), #expr, __FILE__, __LINE__); \
+    } while (0)
+// the reference never checks launches; we do
+#define STM_CHECK_LAUNCH() STM_CHECK(hipGetLastError())
+
+hipStream_t stream();
+
+// ---- grow-only device workspace, bump-allocated per top-level call -----------------
+// The reference hipMalloc/hipFree's ~35 buffers per frame (d_io.cu:43-235); here one
+// cached slab is carved up, so a steady-state frame performs no allocation at all.
+struct Workspace {
+    static void begin(size_t bytes_hint = 0); // start a carve scope (resets the bump pointer)
+    static void *alloc(size_t bytes);         // 256-B aligned; grows (sync + realloc) if needed
+    template <class T> static T *get(size_t n) { return (T *)alloc(n * sizeof(T)); }
+};
+
+// ---- profiling of named kernels with HIP events on the launch stream ----------------
+struct ProfScope {
+    ProfScope(const char *name);
+    ~ProfScope();
+    int slot;
+};
+
+int agg_variant();
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// A cost volume as the kernels see it: either the reference's table of plane pointers
+// (T1 in SURVEY 8a; `tab` is a DEVICE array of D device pointers) or a dense slab
+// [D][H][W] (`base` + d * plane_stride).  One branch per plane access, uniform per wave.
+struct Vol {
+    float *const *tab;
+    float *base;
+    size_t plane_stride;
+    __device__ __forceinline__ float *plane(int d) const { return tab ? tab[d] : base + (size_t)d * plane_stride; }
+};
+static inline Vol vol_table(float **d_tab) { Vol v; v.tab = d_tab; v.base = nullptr; v.plane_stride = 0; return v; }
+static inline Vol vol_slab(float *base, size_t stride) { Vol v; v.tab = nullptr; v.base = base; v.plane_stride = stride; return v; }
+
+// ---- launchers (one per kernel family; definitions next to the kernels) -------------
+// cost init (stm_kernels_cost.hip)
+void launch_pack_bgrx(const u8 *bgr, uint32_t *packed, int H, int W, int elem_sz);
+void launch_census32(const uint32_t *packed, uint32_t *census, int H, int W);
+void launch_cost_init(const uint32_t *pk_l, const uint32_t *pk_r, const uint32_t *cen_l, const uint32_t *cen_r,
+                      Vol cost_l, Vol cost_r, const float *lut_ad, const float *lut_census,
+                      int D, int zd, int H, int W);
+// aggregation (stm_kernels_agg.hip)
+void launch_cross_arms(const uint32_t *packed, u8 *up, u8 *down, u8 *left, u8 *right,
+                       float ucd, float lcd, int usd, int lsd, int H, int W);
+void launch_agg_h(Vol in, Vol out, const u8 *armL, const u8 *armR, int D, int H, int W);
+void launch_agg_v(Vol in, Vol out, const u8 *armU, const u8 *armD, int D, int H, int W, int usd);
+void launch_agg_h_wta(Vol in, const u8 *armL, const u8 *armR, float *disp, int D, int zd, int H, int W);
+void launch_wta(Vol cost, float *disp, int D, int zd, int H, int W);
+// refinement (stm_kernels_refine.hip)
+void launch_dcc(u8 *out_l, u8 *out_r, const float *disp_l, const float *disp_r, u8 *hit_l, u8 *hit_r, int H, int W);
+void launch_irv(float *disp, u8 *outl, const u8 *up, const u8 *down, const u8 *left, const u8 *right,
+                int *max_disp, int *reliable, int thresh_s, float thresh_h,
+                int H, int W, int D, int zd, int usd, int iterations, bool device_flavour);
+void launch_bilateral(const float *in, float *out, const float *spatial, const float *color,
+                      int radius, int H, int W, int D);
+void launch_gaussian_max(const float *in, float *out, const float *spatial, int radius, int H, int W, bool invert_input);
+// DIBR + mux (stm_kernels_dibr.hip)
+void launch_demux_sbs(u8 *l, u8 *r, const u8 *sbs, int H, int Wsbs, int W, int elem_sz);
+void launch_occl(u8 *occl_l, u8 *occl_r, const float *disp_l, const float *disp_r, int H, int W);
+void launch_bleed(const u8 *in, u8 *out, int radius, int H, int W);
+void launch_occl_to_mask(float *mask_l, float *mask_r, const u8 *occl_l, const u8 *occl_r, int H, int W);
+void launch_view_synth(u8 *out, const u8 *img_l, const u8 *img_r, const float *disp_l, const float *disp_r,
+                       const float *mask_l, const float *mask_r, const float *blend, float shift, int H, int W, int elem_sz);
+void launch_fwarp(u8 *out, const u8 *img, const float *disp, float shift, unsigned long long *keys, int H, int W, int elem_sz);
+void launch_view_table(u8 **tab, u8 *first, u8 *last, u8 *mem, size_t stride, int N);
+void launch_mux(const u8 *const *d_views, u8 *out, int N, float y_interval, float inv_y_interval, int ymod,
+                int Hin, int Win, int Hout, int Wout, int elem_sz, int variant);
+// HSLO (stm_kernels_hslo.hip)
+void launch_hslo(Vol cost, Vol acc, const u8 *img_l, const u8 *img_r, float T, float H1, float H2,
+                 int D, int zd, int H, int W, int elem_sz);
+void launch_scale_volume(Vol v, float s, int D, int H, int W);
+
+// host-built tables (same formulas as the reference's host code; see stm_tables.cpp)
+void rho_luts(float ad_coeff, float census_coeff, float *lut_ad /*766*/, float *lut_census /*65*/);
+void gaussian_kernel_2d(float *kernel, int radius, float sigma);
+void gaussian_kernel_1d(float *kernel, int size, float sigma);
+float mux_y_interval(int num_views, float angle, int elem_sz);
+
+} // namespace stm

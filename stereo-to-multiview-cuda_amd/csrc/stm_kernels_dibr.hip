@@ -1,0 +1,247 @@
+// stm_kernels_dibr.hip -- depth-image-based rendering and view multiplexing for gfx950.
+//
+// Reference stages replaced:
+//   demux_sbs                      d_demux_common.cu:8-33
+//   dibr_find_occlusion_kernel     d_dibr_occl.cu:114-128   (hit-map scatter)
+//   filter_bleed_1_kernel          d_filter.cu:105-139
+//   dibr_occl_to_mask_kernel       d_dibr_occl.cu:17-31
+//   dibr_backward_warp_kernel x2 + mux_merge_AB_kernel   d_dibr_bwarp.cu:5-22, d_mux_common.cu:23-46
+//   dibr_forward_warp_kernel       d_dibr_fwarp.cu:9-25     (deterministic here)
+//   mux_multiview_kernel_2 / mux_multiview_kernel        d_mux_multiview.cu:38-84 / :86-124
+// The reference synthesises one view with two warp launches, two temporaries and a merge launch;
+// here one kernel gathers both sources and blends in registers (same arithmetic, same truncations).
+#include "stm_common.h"
+
+namespace stm {
+
+// ------------------------------------------------------------------ side-by-side splitter
+__global__ __launch_bounds__(256) void stm_k_demux_sbs(u8 *__restrict__ l, u8 *__restrict__ r, const u8 *__restrict__ sbs,
+                                                       int H, int Wsbs, int W, int elem_sz)
+{
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= Wsbs) return;
+    const u8 *s = sbs + ((size_t)y * Wsbs + x) * elem_sz;
+    u8 *d;
+    if (x < W) d = l + ((size_t)y * W + x) * elem_sz;
+    else if (x - W < W) d = r + ((size_t)y * W + (x - W)) * elem_sz;
+    else return;
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+}
+void launch_demux_sbs(u8 *l, u8 *r, const u8 *sbs, int H, int Wsbs, int W, int elem_sz)
+{
+    hipLaunchKernelGGL(stm_k_demux_sbs, dim3(cdiv(Wsbs, 256), H), dim3(256), 0, stream(), l, r, sbs, H, Wsbs, W, elem_sz);
+    STM_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ hit maps ("occlusion")
+// occl_r[clamp(x + (int)(dL * 1))] = 1 ; occl_l[clamp(x + (int)(dR * -1))] = 1  (d_dibr_occl.cu:124-127, :156-157)
+__global__ __launch_bounds__(256) void stm_k_occl(u8 *__restrict__ occl_l, u8 *__restrict__ occl_r,
+                                                  const float *__restrict__ disp_l, const float *__restrict__ disp_r, int H, int W)
+{
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    size_t row = (size_t)y * W;
+    int sd = (int)(disp_l[row + x] * 1.0f);
+    occl_r[row + min(max(x + sd, 0), W - 1)] = 1;
+    sd = (int)(disp_r[row + x] * -1.0f);
+    occl_l[row + min(max(x + sd, 0), W - 1)] = 1;
+}
+void launch_occl(u8 *occl_l, u8 *occl_r, const float *disp_l, const float *disp_r, int H, int W)
+{
+    size_t HW = (size_t)H * W;
+    STM_CHECK(hipMemsetAsync(occl_l, 0, HW, stream())); // d_dibr_occl.cu:149-150
+    STM_CHECK(hipMemsetAsync(occl_r, 0, HW, stream()));
+    hipLaunchKernelGGL(stm_k_occl, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), occl_l, occl_r, disp_l, disp_r, H, W);
+    STM_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ majority dilate ("bleed")
+__global__ __launch_bounds__(256) void stm_k_bleed(const u8 *__restrict__ in, u8 *__restrict__ out, int radius, int ksz, int H, int W)
+{
+    int tx = blockIdx.x * 256 + threadIdx.x, ty = blockIdx.y;
+    if (tx >= W) return;
+    u8 va = in[(size_t)ty * W + tx];
+    int cnt = 0;
+    for (int y = -radius; y <= radius; ++y)
+        for (int x = -radius; x <= radius; ++x) {
+            int sx = tx + x, sy = ty + y;
+            if (sx < 0) sx = -sx; // the reference's odd border rule, d_filter.cu:124-127
+            if (sy < 0) sy = -sy;
+            if (sx > W - 1) sx = W - 1 - x;
+            if (sy > H - 1) sy = H - 1 - y;
+            sx = min(max(sx, 0), W - 1); sy = min(max(sy, 0), H - 1);
+            if (in[(size_t)sy * W + sx] > 0) cnt = cnt + 1;
+        }
+    out[(size_t)ty * W + tx] = ((double)cnt > (ksz - 1) * 0.30) ? (u8)1 : va;
+}
+void launch_bleed(const u8 *in, u8 *out, int radius, int H, int W)
+{
+    int ksz = (2 * radius + 1) * (2 * radius + 1);
+    hipLaunchKernelGGL(stm_k_bleed, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), in, out, radius, ksz, H, W);
+    STM_CHECK_LAUNCH();
+}
+
+__global__ __launch_bounds__(256) void stm_k_occl_to_mask(float *__restrict__ ml, float *__restrict__ mr,
+                                                          const u8 *__restrict__ ol, const u8 *__restrict__ orr, size_t HW)
+{
+    size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    ml[p] = ol[p] == 1 ? 1.0f : 0.0f;
+    mr[p] = orr[p] == 1 ? 1.0f : 0.0f;
+}
+void launch_occl_to_mask(float *mask_l, float *mask_r, const u8 *occl_l, const u8 *occl_r, int H, int W)
+{
+    size_t HW = (size_t)H * W;
+    hipLaunchKernelGGL(stm_k_occl_to_mask, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream(), mask_l, mask_r, occl_l, occl_r, HW);
+    STM_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ one synthesised view
+// outL = (u8)(L[sxL] * maskR), sxL = (int)clamp(x + dR * (-shift));  outR = (u8)(R[sxR] * maskL),
+// sxR = (int)clamp(x + dL * (1 - shift))   -- the truncation makes alu_bilinear_interp a nearest fetch
+// (d_dibr_bwarp.cu:16-21, SURVEY A-Q20);  out = (u8)((1-m) * outL) + (u8)(m * outR), u8 wrap (A-Q22).
+__global__ __launch_bounds__(256) void stm_k_view_synth(u8 *__restrict__ out, const u8 *__restrict__ img_l,
+                                                        const u8 *__restrict__ img_r, const float *__restrict__ disp_l,
+                                                        const float *__restrict__ disp_r, const float *__restrict__ mask_l,
+                                                        const float *__restrict__ mask_r, const float *__restrict__ blend,
+                                                        float shift_l, float shift_r, int H, int W, int elem_sz)
+{
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    size_t row = (size_t)y * W, p = row + x;
+    float wmax = (float)(W - 1);
+    float sd = disp_r[p] * shift_l;
+    float fx = (float)x + sd;
+    int sxl = (int)fminf(fmaxf(fx, 0.0f), wmax);
+    sd = disp_l[p] * shift_r;
+    fx = (float)x + sd;
+    int sxr = (int)fminf(fmaxf(fx, 0.0f), wmax);
+    float vmr = mask_r[p], vml = mask_l[p], m = blend[p];
+    float one_m = 1.0f - m;
+    const u8 *sl = img_l + (row + sxl) * elem_sz, *sr = img_r + (row + sxr) * elem_sz;
+    u8 *o = out + p * elem_sz;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        u8 a = (u8)((float)sl[c] * vmr); // left-sourced pixel
+        u8 b = (u8)((float)sr[c] * vml); // right-sourced pixel
+        float cb = one_m * (float)a;
+        float ca = m * (float)b;
+        o[c] = (u8)((u8)cb + (u8)ca);
+    }
+}
+void launch_view_synth(u8 *out, const u8 *img_l, const u8 *img_r, const float *disp_l, const float *disp_r,
+                       const float *mask_l, const float *mask_r, const float *blend, float shift, int H, int W, int elem_sz)
+{
+    float shift_l = -shift;                               // d_dibr_bwarp.cu:56
+    float shift_r = (float)(1.0 - (double)shift);         // :57
+    ProfScope p("view_synth");
+    hipLaunchKernelGGL(stm_k_view_synth, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), out, img_l, img_r, disp_l, disp_r,
+                       mask_l, mask_r, blend, shift_l, shift_r, H, W, elem_sz);
+    STM_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ forward warp (deterministic)
+// The reference scatter is a data race (SURVEY A-Q23).  Rule here: of all sources landing on one target
+// the LARGEST source x wins, which is what a serial ascending-x loop produces.  Pass 1 resolves the
+// winner with atomicMax on a (source x + 1) key per target, pass 2 copies the winner's pixel.
+__global__ __launch_bounds__(256) void stm_k_fwarp_vote(const float *__restrict__ disp, float shift,
+                                                        unsigned long long *__restrict__ keys, int H, int W)
+{
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    size_t row = (size_t)y * W;
+    int sd = (int)(disp[row + x] * shift);
+    int sx = min(max(x + sd, 0), W - 1);
+    atomicMax(&keys[row + sx], (unsigned long long)(x + 1));
+}
+__global__ __launch_bounds__(256) void stm_k_fwarp_copy(u8 *__restrict__ out, const u8 *__restrict__ img,
+                                                        const unsigned long long *__restrict__ keys, int H, int W, int elem_sz)
+{
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    size_t row = (size_t)y * W;
+    unsigned long long k = keys[row + x];
+    u8 *o = out + (row + x) * elem_sz;
+    if (k == 0) { o[0] = 0; o[1] = 0; o[2] = 0; return; } // holes stay 0 (cudaMemset, d_dibr_fwarp.cu:52)
+    const u8 *s = img + (row + (size_t)(k - 1)) * elem_sz;
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+}
+void launch_fwarp(u8 *out, const u8 *img, const float *disp, float shift, unsigned long long *keys, int H, int W, int elem_sz)
+{
+    STM_CHECK(hipMemsetAsync(keys, 0, (size_t)H * W * 8, stream()));
+    hipLaunchKernelGGL(stm_k_fwarp_vote, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), disp, shift, keys, H, W);
+    STM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(stm_k_fwarp_copy, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), out, img, keys, H, W, elem_sz);
+    STM_CHECK_LAUNCH();
+}
+
+// table of view pointers for the interlacer: [0] = right image, [N-1] = left image, rest = synthesised
+__global__ void stm_k_view_table(u8 **tab, u8 *first, u8 *last, u8 *mem, size_t stride, int N)
+{
+    int v = threadIdx.x;
+    if (v >= N) return;
+    tab[v] = v == 0 ? first : (v == N - 1 ? last : mem + (size_t)v * stride);
+}
+void launch_view_table(u8 **tab, u8 *first, u8 *last, u8 *mem, size_t stride, int N)
+{
+    hipLaunchKernelGGL(stm_k_view_table, dim3(1), dim3(64 * ((N + 63) / 64)), 0, stream(), tab, first, last, mem, stride, N);
+    STM_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ multiview interlacer
+// fast_bilinear_interp, d_mux_multiview.cu:10-36 (floor, +1 neighbour clamped, u8 truncation)
+__device__ __forceinline__ u8 bilinear_u8(const u8 *__restrict__ data, int elem_sz, int off, float cx, float cy, int width, int height)
+{
+    int x0 = (int)floorf(cx), y0 = (int)floorf(cy);
+    int x1 = min(x0 + 1, width - 1), y1 = min(y0 + 1, height - 1);
+    float wx = cx - (float)x0, wy = cy - (float)y0;
+    float v00 = (float)data[((size_t)x0 + (size_t)y0 * width) * elem_sz + off];
+    float v01 = (float)data[((size_t)x1 + (size_t)y0 * width) * elem_sz + off];
+    float v10 = (float)data[((size_t)x0 + (size_t)y1 * width) * elem_sz + off];
+    float v11 = (float)data[((size_t)x1 + (size_t)y1 * width) * elem_sz + off];
+    float a = v00 * (1.0f - wx);
+    float b = v01 * wx;
+    float top = a + b;
+    a = v10 * (1.0f - wx);
+    b = v11 * wx;
+    float bot = a + b;
+    a = top * (1.0f - wy);
+    b = bot * wy;
+    return (u8)(a + b);
+}
+
+__global__ __launch_bounds__(256) void stm_k_mux(const u8 *const *__restrict__ views, u8 *__restrict__ out, int N,
+                                                 float y_interval, float inv_y, int ymod, int Hin, int Win, int Hout,
+                                                 int Wout, int elem_sz, int variant)
+{
+    int tx = blockIdx.x * 256 + threadIdx.x, ty = blockIdx.y;
+    if (tx >= Wout) return;
+    float xs = ((float)tx / (float)Wout) * (float)Win;
+    xs = fminf(fmaxf(xs, 0.0f), (float)(Win - 1));
+    float ys = ((float)ty / (float)Hout) * (float)Hin;
+    ys = fminf(fmaxf(ys, 0.0f), (float)(Hin - 1));
+    float x_interval = (float)N;
+    float y_view = (float)(ty % ymod) + 1.0f;
+    y_view = y_view * x_interval;
+    y_view = (variant == 2) ? y_view * inv_y : y_view / y_interval; // :62-63 vs :105-106
+    int x_view = (tx * 3 + (int)y_view) % N;
+    int r_view = x_view;
+    if (r_view < 0) r_view += N;
+    int g_view = r_view + 1, b_view = r_view + 2;
+    if (g_view >= N) g_view -= N;
+    if (b_view >= N) b_view -= N;
+    size_t o = ((size_t)tx + (size_t)ty * Wout) * elem_sz;
+    out[o + 0] = bilinear_u8(views[b_view], elem_sz, 0, xs, ys, Win, Hin);
+    out[o + 1] = bilinear_u8(views[g_view], elem_sz, 1, xs, ys, Win, Hin);
+    out[o + 2] = bilinear_u8(views[r_view], elem_sz, 2, xs, ys, Win, Hin);
+}
+void launch_mux(const u8 *const *d_views, u8 *out, int N, float y_interval, float inv_y_interval, int ymod, int Hin,
+                int Win, int Hout, int Wout, int elem_sz, int variant)
+{
+    ProfScope p("mux");
+    hipLaunchKernelGGL(stm_k_mux, dim3(cdiv(Wout, 256), Hout), dim3(256), 0, stream(), d_views, out, N, y_interval,
+                       inv_y_interval, ymod, Hin, Win, Hout, Wout, elem_sz, variant);
+    STM_CHECK_LAUNCH();
+}
+
+} // namespace stm

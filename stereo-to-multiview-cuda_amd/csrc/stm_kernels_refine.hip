@@ -1,0 +1,240 @@
+// stm_kernels_refine.hip -- disparity refinement for gfx950: L/R consistency check, iterative region
+// voting, bilateral filter on the disparity map, grow-only gaussian.
+//
+// Reference stages replaced:
+//   dr_dcc_kernel / dr_ddc_kernel / dr_merge_errors_kernel   d_dr_dcc.cu:57-82 / :35-54 / :18-33
+//   dr_irv_pre_kernel / dr_irv_kernel_3                      d_dr_irv.cu:134-220 / :17-43
+//   filter_bilateral_1_kernel_6                              d_filter_bilateral.cu:222-304
+//   filter_gaussian_1_kernel_1 (+ op_invertnormf_kernel)     d_filter_gaussian.cu:9-88 (d_op.cu:7-16)
+// All of them are image-sized (<= 17 B/px of HBM traffic) and LDS/latency bound; accumulation orders
+// follow the reference loops exactly (row-major taps, sequential float adds, no contraction).
+#include "stm_common.h"
+
+namespace stm {
+
+// ------------------------------------------------------------------ L/R check
+// phase 1: outlier flags + hit-map scatter (both scatters only ever write the value 0 -> benign races)
+__global__ __launch_bounds__(256) void stm_k_dcc_mark(u8 *__restrict__ out_l, u8 *__restrict__ out_r,
+                                                      const float *__restrict__ disp_l, const float *__restrict__ disp_r,
+                                                      u8 *__restrict__ hit_l, u8 *__restrict__ hit_r, int H, int W)
+{
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    size_t row = (size_t)y * W;
+    const float thresh = 1.0f; // d_dr_dcc.cu:117
+    float dl = disp_l[row + x];
+    int c = min(max(x + (int)dl, 0), W - 1);
+    if (fabsf(dl - disp_r[row + c]) > thresh) out_l[row + x] = 1;
+    hit_r[row + c] = 0; // dr_ddc_kernel: same coordinate (d_dr_dcc.cu:45-48)
+    float dr = disp_r[row + x];
+    c = min(max(x - (int)dr, 0), W - 1);
+    if (fabsf(dr - disp_l[row + c]) > thresh) out_r[row + x] = 1;
+    hit_l[row + c] = 0;
+}
+// phase 2: outlier and never hit -> class 2 (occlusion)
+__global__ __launch_bounds__(256) void stm_k_dcc_merge(u8 *__restrict__ out_l, u8 *__restrict__ out_r,
+                                                       const u8 *__restrict__ hit_l, const u8 *__restrict__ hit_r, size_t HW)
+{
+    size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    if (out_l[p] == 1 && hit_l[p] == 1) out_l[p] = 2;
+    if (out_r[p] == 1 && hit_r[p] == 1) out_r[p] = 2;
+}
+
+void launch_dcc(u8 *out_l, u8 *out_r, const float *disp_l, const float *disp_r, u8 *hit_l, u8 *hit_r, int H, int W)
+{
+    size_t HW = (size_t)H * W;
+    STM_CHECK(hipMemsetAsync(hit_l, 1, HW, stream())); // d_dr_dcc.cu:107,111
+    STM_CHECK(hipMemsetAsync(hit_r, 1, HW, stream()));
+    hipLaunchKernelGGL(stm_k_dcc_mark, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), out_l, out_r, disp_l, disp_r, hit_l,
+                       hit_r, H, W);
+    STM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(stm_k_dcc_merge, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream(), out_l, out_r, hit_l,
+                       hit_r, HW);
+    STM_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------ iterative region voting
+// One thread per pixel; only outlier pixels vote.  The histogram has max(D,65) bins (the reference's
+// fixed int[65] overflows for D > 65, SURVEY A-Q17 ii) of u16 per thread in LDS, laid out
+// [bin][thread] so a wave's increments hit 64 distinct addresses.
+constexpr int IRV_T = 64;
+__global__ __launch_bounds__(IRV_T) void stm_k_irv_vote(const float *__restrict__ disp, const u8 *__restrict__ outl,
+                                                        const u8 *__restrict__ aU, const u8 *__restrict__ aD,
+                                                        const u8 *__restrict__ aL, const u8 *__restrict__ aR,
+                                                        int *__restrict__ max_disp, int *__restrict__ reliable,
+                                                        int H, int W, int nb, int zd, int usd)
+{
+    extern __shared__ uint16_t hist[]; // [nb][IRV_T]
+    int tx = threadIdx.x;
+    int gx = blockIdx.x * IRV_T + tx, gy = blockIdx.y;
+    if (gx >= W) return;
+    size_t p = (size_t)gy * W + gx;
+    if (outl[p] == 0) return;
+    for (int i = 0; i < nb; ++i) hist[i * IRV_T + tx] = 0;
+    int cu = aU[p], cd = aD[p];
+    if (cu > usd) cu = usd; // d_dr_irv.cu:179-180
+    int max_bin = 0, max_d = (int)disp[p], total = 0;
+    for (int y = -cu; y <= cd; ++y) { // inclusive window (SURVEY A-Q17 iii)
+        size_t q = (size_t)(gy + y) * W + gx;
+        int cl = aL[q], cr = aR[q];
+        for (int x = -cl; x <= cr; ++x) {
+            size_t s = q + x; // arms never leave the image, so the reference's clamp is the identity
+            if (outl[s] == 0) {
+                int b = (int)disp[s] + zd;
+                if (b >= 0 && b < nb) hist[b * IRV_T + tx]++;
+                total++;
+            }
+        }
+    }
+    for (int i = 0; i < nb; ++i) {
+        int c = hist[i * IRV_T + tx];
+        if (max_bin < c) { max_bin = c; max_d = i - zd; }
+    }
+    max_disp[p] = max_d;
+    reliable[p] = total;
+}
+
+__global__ __launch_bounds__(256) void stm_k_irv_apply(float *__restrict__ disp, u8 *__restrict__ outl,
+                                                       const int *__restrict__ max_disp, int *__restrict__ reliable,
+                                                       int thresh_s, float thresh_h, int zd, size_t HW)
+{
+    size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    if (outl[p] != 0) {
+        int tr = reliable[p], md = max_disp[p];
+        // ratio uses the winning BIN INDEX, not its count (d_dr_irv.cu:36, SURVEY A-Q17 iv)
+        if (tr > thresh_s && (float)(md + zd) / (float)tr > thresh_h) {
+            outl[p] = 0;
+            reliable[p] = tr + 1;
+            disp[p] = (float)md;
+        }
+    }
+}
+
+void launch_irv(float *disp, u8 *outl, const u8 *up, const u8 *down, const u8 *left, const u8 *right, int *max_disp,
+                int *reliable, int thresh_s, float thresh_h, int H, int W, int D, int zd, int usd, int iterations,
+                bool device_flavour)
+{
+    size_t HW = (size_t)H * W;
+    int nb = D > 65 ? D : 65;
+    size_t smem = (size_t)nb * IRV_T * 2;
+    auto vote = [&]() {
+        ProfScope p("irv_vote");
+        hipLaunchKernelGGL(stm_k_irv_vote, dim3(cdiv(W, IRV_T), H), dim3(IRV_T), smem, stream(), disp, outl, up, down, left,
+                           right, max_disp, reliable, H, W, nb, zd, usd);
+        STM_CHECK_LAUNCH();
+    };
+    auto apply = [&]() {
+        hipLaunchKernelGGL(stm_k_irv_apply, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream(), disp, outl, max_disp,
+                           reliable, thresh_s, thresh_h, zd, HW);
+        STM_CHECK_LAUNCH();
+    };
+    if (device_flavour) { // d_dr_irv.cu:259-265
+        for (int i = 0; i < iterations; ++i) { vote(); apply(); }
+    } else { // d_dr_irv.cu:344-353
+        vote();
+        for (int i = 0; i < iterations; ++i) apply();
+    }
+}
+
+// ------------------------------------------------------------------ stencils
+constexpr int ST_TX = 64, ST_TY = 4;
+
+// bilateral: w = Gs[dx,dy] * Gc[(int)|v0 - v|], out = sum(w v) / sum(w)   (d_filter_bilateral.cu:278-303)
+__global__ __launch_bounds__(ST_TX *ST_TY) void stm_k_bilateral(const float *__restrict__ in, float *__restrict__ out,
+                                                               const float *__restrict__ spatial,
+                                                               const float *__restrict__ color, int radius, int H, int W,
+                                                               int ncolor)
+{
+    extern __shared__ float sm[];
+    const int tw = ST_TX + 2 * radius, th = ST_TY + 2 * radius, kw = 2 * radius + 1;
+    float *tile = sm, *sk = sm + tw * th, *ck = sk + kw * kw;
+    int tid = threadIdx.y * ST_TX + threadIdx.x;
+    int x0 = blockIdx.x * ST_TX, y0 = blockIdx.y * ST_TY;
+    for (int i = tid; i < tw * th; i += ST_TX * ST_TY) {
+        int ty = i / tw, tx = i - ty * tw;
+        int gx = min(max(x0 + tx - radius, 0), W - 1), gy = min(max(y0 + ty - radius, 0), H - 1);
+        tile[i] = in[(size_t)gy * W + gx];
+    }
+    for (int i = tid; i < kw * kw; i += ST_TX * ST_TY) sk[i] = spatial[i];
+    for (int i = tid; i < ncolor; i += ST_TX * ST_TY) ck[i] = color[i];
+    __syncthreads();
+    int gx = x0 + threadIdx.x, gy = y0 + threadIdx.y;
+    if (gx >= W || gy >= H) return;
+    float va = tile[(threadIdx.y + radius) * tw + threadIdx.x + radius];
+    float norm = 0.0f, res = 0.0f;
+    for (int y = 0; y < kw; ++y) {
+        const float *trow = tile + (threadIdx.y + y) * tw + threadIdx.x;
+        const float *krow = sk + y * kw;
+        for (int x = 0; x < kw; ++x) {
+            float vs = trow[x];
+            int ci = (int)fabsf(va - vs);
+            ci = min(ci, ncolor - 1);
+            float w = krow[x] * ck[ci];
+            norm = norm + w;
+            float t = vs * w;
+            res = res + t;
+        }
+    }
+    out[(size_t)gy * W + gx] = res / norm;
+}
+
+void launch_bilateral(const float *in, float *out, const float *spatial, const float *color, int radius, int H, int W,
+                      int D)
+{
+    int tw = ST_TX + 2 * radius, th = ST_TY + 2 * radius, kw = 2 * radius + 1;
+    size_t smem = (size_t)(tw * th + kw * kw + D) * 4;
+    ProfScope p("bilateral");
+    hipLaunchKernelGGL(stm_k_bilateral, dim3(cdiv(W, ST_TX), cdiv(H, ST_TY)), dim3(ST_TX, ST_TY), smem, stream(), in, out,
+                       spatial, color, radius, H, W, D);
+    STM_CHECK_LAUNCH();
+}
+
+// grow-only gaussian: out = max(in, blur(in)); INVERT fuses op_invertnormf (x -> 1 - x) into the tile load
+__global__ __launch_bounds__(ST_TX *ST_TY) void stm_k_gaussian_max(const float *__restrict__ in, float *__restrict__ out,
+                                                                  const float *__restrict__ spatial, int radius, int H,
+                                                                  int W, int invert)
+{
+    extern __shared__ float sm[];
+    const int tw = ST_TX + 2 * radius, th = ST_TY + 2 * radius, kw = 2 * radius + 1;
+    float *tile = sm, *sk = sm + tw * th;
+    int tid = threadIdx.y * ST_TX + threadIdx.x;
+    int x0 = blockIdx.x * ST_TX, y0 = blockIdx.y * ST_TY;
+    for (int i = tid; i < tw * th; i += ST_TX * ST_TY) {
+        int ty = i / tw, tx = i - ty * tw;
+        int gx = min(max(x0 + tx - radius, 0), W - 1), gy = min(max(y0 + ty - radius, 0), H - 1);
+        float v = in[(size_t)gy * W + gx];
+        tile[i] = invert ? 1.0f - v : v;
+    }
+    for (int i = tid; i < kw * kw; i += ST_TX * ST_TY) sk[i] = spatial[i];
+    __syncthreads();
+    int gx = x0 + threadIdx.x, gy = y0 + threadIdx.y;
+    if (gx >= W || gy >= H) return;
+    float va = tile[(threadIdx.y + radius) * tw + threadIdx.x + radius];
+    float norm = 0.0f, res = 0.0f;
+    for (int y = 0; y < kw; ++y) {
+        const float *trow = tile + (threadIdx.y + y) * tw + threadIdx.x;
+        const float *krow = sk + y * kw;
+        for (int x = 0; x < kw; ++x) {
+            float w = krow[x];
+            norm = norm + w;
+            float t = trow[x] * w;
+            res = res + t;
+        }
+    }
+    float q = res / norm;
+    out[(size_t)gy * W + gx] = (va < q) ? q : va; // d_filter_gaussian.cu:84-87
+}
+
+void launch_gaussian_max(const float *in, float *out, const float *spatial, int radius, int H, int W, bool invert_input)
+{
+    int tw = ST_TX + 2 * radius, th = ST_TY + 2 * radius, kw = 2 * radius + 1;
+    size_t smem = (size_t)(tw * th + kw * kw) * 4;
+    ProfScope p("gaussian_max");
+    hipLaunchKernelGGL(stm_k_gaussian_max, dim3(cdiv(W, ST_TX), cdiv(H, ST_TY)), dim3(ST_TX, ST_TY), smem, stream(), in, out,
+                       spatial, radius, H, W, invert_input ? 1 : 0);
+    STM_CHECK_LAUNCH();
+}
+
+} // namespace stm

@@ -1,0 +1,215 @@
+// stm_runtime.hip -- error policy, current stream, cached workspace, event profiler,
+// host-built lookup tables.  Replaces cuda_utils.h (reference) for the HIP build.
+#include "stm_common.h"
+#include "../../include/stm_hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace stm {
+
+// ------------------------------------------------------------------ errors
+static int g_error_mode = 0;
+static thread_local std::string g_last_error;
+
+void fail(const char *what, const char *expr, const char *file, int line)
+{
+    char buf[1024];
+    snprintf(buf, sizeof buf, "HIP error at: %s:%d\n%s %s", file, line, what, expr);
+    g_last_error = buf;
+    fprintf(stderr, "%s\n", buf);
+    if (g_error_mode == 0)
+        exit(1); // cuda_utils.h:15-20
+}
+
+// ------------------------------------------------------------------ stream
+static thread_local hipStream_t g_stream = nullptr;
+hipStream_t stream() { return g_stream; }
+
+// --------------------------------------------------------------- workspace
+// one slab per device; grows geometrically, never shrinks until stm_release_workspace
+struct WsState {
+    char *base = nullptr;
+    size_t cap = 0;
+    size_t off = 0;
+    std::vector<void *> retired; // old slabs still possibly referenced by in-flight kernels
+};
+static WsState g_ws[16];
+
+static WsState &ws()
+{
+    int dev = 0;
+    STM_CHECK(hipGetDevice(&dev));
+    return g_ws[dev & 15];
+}
+
+void Workspace::begin(size_t hint)
+{
+    WsState &w = ws();
+    w.off = 0;
+    if (hint > w.cap) {
+        // grow before carving so that one scope never straddles two slabs
+        if (w.base) {
+            STM_CHECK(hipStreamSynchronize(stream()));
+            STM_CHECK(hipFree(w.base));
+        }
+        size_t cap = hint + (hint >> 3) + (1u << 20);
+        STM_CHECK(hipMalloc((void **)&w.base, cap));
+        w.cap = cap;
+    }
+}
+
+void *Workspace::alloc(size_t bytes)
+{
+    WsState &w = ws();
+    size_t a = (w.off + 255) & ~(size_t)255;
+    if (a + bytes > w.cap) {
+        // Late growth: earlier carve-outs of this scope live in the old slab and kernels
+        // may be in flight on them, so retire (do not free) it until release.
+        size_t cap = (a + bytes) * 2 + (1u << 20);
+        char *nb = nullptr;
+        STM_CHECK(hipMalloc((void **)&nb, cap));
+        if (w.base) w.retired.push_back(w.base);
+        w.base = nb;
+        w.cap = cap;
+        a = 0;
+    }
+    w.off = a + bytes;
+    return w.base + a;
+}
+
+static void ws_release()
+{
+    WsState &w = ws();
+    STM_CHECK(hipDeviceSynchronize());
+    for (void *p : w.retired) STM_CHECK(hipFree(p));
+    w.retired.clear();
+    if (w.base) STM_CHECK(hipFree(w.base));
+    w.base = nullptr;
+    w.cap = w.off = 0;
+}
+
+// ---------------------------------------------------------------- profiler
+struct ProfRec {
+    std::string name;
+    hipEvent_t a, b;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+
+ProfScope::ProfScope(const char *name) : slot(-1)
+{
+    if (!g_prof_on) return;
+    ProfRec r;
+    r.name = name;
+    if (!g_prof_pool.empty()) {
+        r.a = g_prof_pool.back().first;
+        r.b = g_prof_pool.back().second;
+        g_prof_pool.pop_back();
+    } else {
+        STM_CHECK(hipEventCreate(&r.a));
+        STM_CHECK(hipEventCreate(&r.b));
+    }
+    STM_CHECK(hipEventRecord(r.a, stream()));
+    slot = (int)g_prof.size();
+    g_prof.push_back(r);
+}
+ProfScope::~ProfScope()
+{
+    if (slot >= 0) STM_CHECK(hipEventRecord(g_prof[slot].b, stream()));
+}
+
+static int g_agg_variant = 0;
+int agg_variant() { return g_agg_variant; }
+
+// ------------------------------------------------------------------ tables
+// rho(c) = 1 - exp(-c/lambda): d_ci_adcensus.cu:27-34 with inv = 1.0/coeff narrowed (:160).
+// The reference's __expf is replaced by a correctly rounded exp evaluated on the host once per
+// distinct input: the AD term takes only 766 values ((|dB|+|dG|+|dR|) * 0.33333334f, d_ci_ad.cu:146-157),
+// the census term 65 (Hamming 0..64, d_alu.cu:7-15).  The kernels index these tables, so CPU and GPU
+// cost volumes agree bit for bit (SURVEY A-Q8).
+static inline float rho(float c, float inv)
+{
+    float t = -c * inv;
+    float e = (float)exp((double)t);
+    return (float)(1.0 - (double)e);
+}
+void rho_luts(float ad_coeff, float census_coeff, float *lut_ad, float *lut_census)
+{
+    float inv_ad = (float)(1.0 / (double)ad_coeff);
+    float inv_c = (float)(1.0 / (double)census_coeff);
+    for (int k = 0; k <= 765; ++k) lut_ad[k] = rho((float)k * 0.33333334f, inv_ad);
+    for (int h = 0; h <= 64; ++h) lut_census[h] = rho((float)h, inv_c);
+}
+// generateGaussianKernel / gaussian2D: d_filter_gaussian.cu:237-255 (PI literal :7)
+void gaussian_kernel_2d(float *kernel, int radius, float sigma)
+{
+    const float PI = 3.14159265359f;
+    int kw = radius * 2 + 1;
+    for (int y = -radius; y <= radius; ++y)
+        for (int x = -radius; x <= radius; ++x) {
+            float fx = (float)x, fy = (float)y;
+            float variance = (float)pow((double)sigma, 2.0);
+            float exponent = (float)(-(pow((double)fx, 2.0) + pow((double)fy, 2.0)) / (double)(2 * variance));
+            kernel[(x + radius) + (y + radius) * kw] = expf(exponent) / (2 * PI * variance);
+        }
+}
+// generateGaussian1D / gaussian1D_host: d_filter_bilateral.cu:26-39 (PI literal :8)
+void gaussian_kernel_1d(float *kernel, int size, float sigma)
+{
+    const float PI = 3.14159265359f;
+    for (int i = 0; i < size; ++i) {
+        float x = (float)i;
+        float variance = (float)pow((double)sigma, 2.0);
+        float power = (float)pow((double)x, 2.0);
+        float exponent = -power / (2 * variance);
+        kernel[i] = expf(exponent) / sqrtf(2 * PI * variance);
+    }
+}
+// y_interval: d_mux_multiview.cu:146 (PI literal :8)
+float mux_y_interval(int num_views, float angle, int elem_sz)
+{
+    const float PI = 3.1415926535f;
+    float a = angle * PI;
+    double t = tan((double)a / 180.0);
+    return (float)((double)(float)num_views / t / (double)(float)elem_sz);
+}
+
+} // namespace stm
+
+// ------------------------------------------------------------------- C ABI
+extern "C" {
+int stm_version(void) { return 100; }
+void stm_set_stream(void *s) { stm::g_stream = (hipStream_t)s; }
+void *stm_get_stream(void) { return (void *)stm::g_stream; }
+void stm_set_error_mode(int m) { stm::g_error_mode = m; }
+const char *stm_last_error(void) { return stm::g_last_error.c_str(); }
+void stm_release_workspace(void) { stm::ws_release(); }
+void stm_prof_enable(int on) { stm::g_prof_on = on != 0; }
+void stm_prof_reset(void)
+{
+    for (auto &r : stm::g_prof) stm::g_prof_pool.push_back({r.a, r.b});
+    stm::g_prof.clear();
+}
+int stm_prof_read(const char *kernel, float *total_ms)
+{
+    int n = 0;
+    float tot = 0.f;
+    for (auto &r : stm::g_prof) {
+        if (r.name != kernel) continue;
+        STM_CHECK(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        STM_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+        tot += ms;
+        ++n;
+    }
+    if (total_ms) *total_ms = tot;
+    return n;
+}
+void stm_set_agg_variant(int v) { stm::g_agg_variant = v; }
+}

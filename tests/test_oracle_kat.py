@@ -1,0 +1,204 @@
+"""CPU tests of the oracle: hand-computable known answers, the degenerate identical
+pair, and the committed golden vectors.  No GPU, no HIP library."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REF_IMG, rand_pair
+
+
+def test_hamdist_kats(orc):
+    # alu_hamdist_64 keeps the low 32 bits and weighs bit 31 by 33 (d_alu.cu:7-15, SURVEY A-Q1)
+    assert orc.hamdist64(0, 0x80000000) == 33
+    assert orc.hamdist64(0, 1 << 32) == 0
+    assert orc.hamdist64(0, 0x7FFFFFFF) == 31
+    assert orc.hamdist64(0, 0xFFFFFFFF) == 64
+    assert orc.hamdist64(0xFFFF00000000, 0) == 0
+    rng = np.random.RandomState(1)
+    for _ in range(200):
+        a, b = int(rng.randint(0, 2 ** 48, dtype=np.int64)), int(rng.randint(0, 2 ** 48, dtype=np.int64))
+        assert orc.hamdist64(a, b) == orc.hamdist64_closed(a, b)
+
+
+def test_grey_kats(orc):
+    img = np.zeros((2, 2, 3), np.uint8)
+    img[0, 0] = (255, 255, 255)
+    img[0, 1] = (3, 3, 3)
+    img[1, 0] = (1, 0, 0)
+    img[1, 1] = (10, 20, 30)
+    g = orc.grey(img)
+    assert g[0, 0] == 255 and g[1, 0] == 0
+    # three rounded products then truncation (d_mux_common.cu:16-20)
+    c = np.float32(0.33333334)
+    for (y, x) in [(0, 1), (1, 1)]:
+        b, gg, r = [np.float32(v) * c for v in img[y, x]]
+        assert g[y, x] == int(np.float32(np.float32(b + gg) + r))
+
+
+def test_census_constant_image_is_zero(orc):
+    g = np.full((20, 30), 77, np.uint8)
+    assert not orc.census(g).any()
+
+
+def test_census_bit_layout(orc):
+    # one darker pixel at (y-1, x-4) relative to the centre -> sequence number 16 -> bit 31 of the low word
+    g = np.full((15, 15), 100, np.uint8)
+    g[6, 3] = 10
+    c = orc.census(g)
+    assert c[7, 7] == 1 << 31
+    # (y+3, x+4) is the last appended bit -> bit 0 ; (y-3, x-4) is the first -> bit 47
+    g = np.full((15, 15), 100, np.uint8); g[10, 11] = 10
+    assert orc.census(g)[7, 7] == 1
+    g = np.full((15, 15), 100, np.uint8); g[4, 3] = 10
+    assert orc.census(g)[7, 7] == 1 << 47
+    # centre row and column are skipped entirely (x != 0 && y != 0, d_ci_census.cu:41)
+    g = np.full((15, 15), 100, np.uint8); g[7, 3] = 10; g[4, 7] = 10
+    assert orc.census(g)[7, 7] == 0
+
+
+def test_arms_constant_image(orc):
+    H, W, usd = 23, 31, 9
+    img = np.full((H, W, 3), 50, np.uint8)
+    x = orc.cross_arms(img, 6, 20, usd, 4)
+    yy, xx = np.mgrid[0:H, 0:W]
+    assert np.array_equal(x[0], np.minimum(usd, yy))
+    assert np.array_equal(x[1], np.minimum(usd, H - 1 - yy))
+    assert np.array_equal(x[2], np.minimum(usd, xx))
+    assert np.array_equal(x[3], np.minimum(usd, W - 1 - xx))
+
+
+def test_arm_includes_first_failing_pixel(orc):
+    # value recorded before the colour test (SURVEY A-Q9): a step edge 3 px to the right gives arm 3, not 2
+    img = np.full((5, 20, 3), 50, np.uint8)
+    img[:, 10:] = 200
+    x = orc.cross_arms(img, 6, 20, 9, 4)
+    assert x[3][2, 7] == 3 and x[3][2, 9] == 1 and x[2][2, 10] == 1
+
+
+def test_hsum_all_ones_is_arm_sum(orc):
+    L, _ = rand_pair(24, 40, 3)
+    x = orc.cross_arms(L, 6, 20, 9, 4)
+    ones = np.ones((3, 24, 40), np.float32)
+    h = orc.agg_hpass(ones, x)
+    v = orc.agg_vpass(ones, x)
+    assert np.array_equal(h[1], (x[2].astype(np.float32) + x[3]))  # half-open window: armL + armR elements
+    assert np.array_equal(v[2], (x[0].astype(np.float32) + x[1]))
+
+
+def test_wta_first_lowest_wins(orc):
+    c = np.ones((5, 2, 3), np.float32)
+    c[3, 0, 0] = 0.5
+    c[1, 0, 1] = 0.5
+    c[4, 0, 1] = 0.5  # tie with d=1 -> d=1 wins (strict >, d_dc_wta.cu:28)
+    d = orc.dc_wta(c, 2)
+    assert d[0, 0] == 1 and d[0, 1] == -1 and d[1, 2] == -2
+
+
+def test_fish_identical_pair_known_answer(orc, golden):
+    F, D, zd = golden["fish"], int(golden["params"][0]), int(golden["params"][1])
+    cl, cr = orc.ci_adcensus(F, F, 10, 30, D, zd)
+    assert np.array_equal(cl, golden["fish_cost_l"])
+    assert not cl[zd].any() and not cr[zd].any()  # AD = 0 and census = 0 at zero offset
+    x, a = orc.ca_cross(F, cl, 6, 20, 9, 4)
+    assert not a[zd].any()
+    disp = orc.dc_wta(a, zd)
+    assert (disp <= 0).all()  # strict '>' picks the first zero, which is at or below zd
+
+
+def test_dcc_classes(orc):
+    dl = np.zeros((1, 8), np.float32)
+    dr = np.zeros((1, 8), np.float32)
+    dl[0, 2] = 3
+    ol, orr = orc.dr_dcc(dl, dr)
+    # L(2) -> R(5): |3 - 0| > 1 -> outlier.  Every dR = 0 maps x -> x, so L(2) is still hit -> class 1 (mismatch).
+    assert ol[0, 2] == 1 and ol.sum() == 1
+    # R(2) -> L(2): |0 - 3| > 1 -> outlier; L(2) maps to R(5), so nothing lands on R(2) -> class 2 (occlusion).
+    assert orr[0, 2] == 2 and orr.sum() == 2
+
+
+def test_gaussian_tables(orc):
+    k = orc.gaussian_kernel_2d(2, 1.5)
+    assert k.shape == (5, 5) and np.allclose(k, k.T) and k[2, 2] == k.max()
+    v = np.float32(1.5) ** 2
+    assert np.isclose(k[2, 2], 1.0 / (2 * np.float32(3.14159265359) * v), rtol=1e-6)
+    k1 = orc.gaussian_kernel_1d(8, 5.0)
+    assert np.all(np.diff(k1) < 0)
+
+
+def test_bleed_rule(orc):
+    img = np.zeros((7, 7), np.uint8)
+    img[3, 2:5] = 1  # three set pixels in the 3x3 window of (3,3) and of (2,3)/(4,3)
+    out = orc.filter_bleed_1(img, 1)
+    assert out[2, 3] == 1 and out[4, 3] == 1 and out[0, 0] == 0
+
+
+def test_mux_view_pattern(orc):
+    N, H, W = 8, 16, 32
+    views = [np.full((H, W, 3), v * 10, np.uint8) for v in range(N)]
+    out = orc.mux_multiview(views, 18.43, H, W, 2)
+    yi = orc.mux_y_interval(N, 18.43)
+    assert abs(yi - 8.0) < 0.05
+    # r_view = (3*tx + int(yv)) % N, g = r+1, b = r+2 (d_mux_multiview.cu:60-73); channels are B,G,R
+    for ty in (0, 5):
+        for tx in (0, 1, 7, 31):
+            yv = np.float32(np.float32(ty % int(round(yi)) + 1.0) * np.float32(N)) * np.float32(np.float32(1.0) / np.float32(yi))
+            r = (tx * 3 + int(yv)) % N
+            assert tuple(out[ty, tx]) == (((r + 2) % N) * 10, ((r + 1) % N) * 10, r * 10)
+
+
+def test_golden_vectors_regression(orc, golden):
+    """The oracle must keep reproducing the committed vectors (generated by tests/golden/make_golden.py)."""
+    g = golden
+    D, zd, ad, ce, ucd, lcd, usd, lsd, ts, th, N, angle = g["params"]
+    D, zd, usd, lsd, ts, N = int(D), int(zd), int(usd), int(lsd), int(ts), int(N)
+    L, R = g["L"], g["R"]
+    assert np.array_equal(orc.grey(L), g["grey_l"])
+    assert np.array_equal(orc.census(g["grey_l"]), g["census_l"])
+    cl, cr = orc.ci_adcensus(L, R, ad, ce, D, zd)
+    assert np.array_equal(cl, g["cost_l"]) and np.array_equal(cr, g["cost_r"])
+    xl, al = orc.ca_cross(L, cl, ucd, lcd, usd, lsd)
+    assert np.array_equal(xl, g["cross_l"]) and np.array_equal(al, g["acost_l"])
+    assert np.array_equal(orc.dc_wta(al, zd), g["wta_l"])
+    ol, orr = orc.dr_dcc(g["wta_l"], g["wta_r"])
+    assert np.array_equal(ol, g["outl_l"]) and np.array_equal(orr, g["outl_r"])
+    il, iol = orc.dr_irv(g["wta_l"], ol, xl, ts, th, D, zd, usd, 5, True)
+    assert np.array_equal(il, g["irv_l"]) and np.array_equal(iol, g["irv_outl_l"])
+    assert np.array_equal(orc.filter_bilateral_1(il, 7, 5.0, 10.0, D), g["bil_l"])
+    sbs = np.ascontiguousarray(np.concatenate([L, R], axis=1))
+    fr = orc.adcensus_stm(sbs, L.shape[0], L.shape[1], N, angle, D, zd, ad, ce, ucd, lcd, usd, lsd, ts, th)
+    assert np.array_equal(fr["interlaced"], g["frame_mux"]) and np.array_equal(fr["disp_l"], g["frame_disp_l"])
+
+
+def test_cost_init_lut_equals_direct(orc):
+    """rho via the 766/65-entry tables (what the HIP path indexes) == rho evaluated per pixel."""
+    L, R = rand_pair(20, 33, 5)
+    la, lc = orc.rho_luts(10.0, 30.0)
+    cl, cr = orc.ci_adcensus(L, R, 10.0, 30.0, 6, 3)
+    g_l, g_r = orc.grey(L), orc.grey(R)
+    c_l, c_r = orc.census(g_l), orc.census(g_r)
+    H, W = g_l.shape
+    for d in (0, 3, 5):
+        o = d - 3
+        xr = np.clip(np.arange(W) + o, 0, W - 1)
+        ad = np.abs(L.astype(np.int32) - R[:, xr].astype(np.int32)).sum(axis=2)
+        x = (c_l ^ c_r[:, xr]).astype(np.uint64) & np.uint64(0xFFFFFFFF)
+        ham = np.array([[bin(int(v) & 0x7FFFFFFF).count("1") + 33 * (int(v) >> 31) for v in row] for row in x])
+        assert np.array_equal(cl[d], la[ad] + lc[ham])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_IMG), reason="reference img/ only exists in the build container")
+def test_bud_pair_matches_survey_understanding_check(orc, stm):
+    """background plateau at offset -6 (~52 %), mean arm ~9 px, L/R outliers ~14.5 %."""
+    L = stm.bmp_io.read_bmp(os.path.join(REF_IMG, "bud_2.bmp"))
+    R = stm.bmp_io.read_bmp(os.path.join(REF_IMG, "bud_3.bmp"))
+    assert L.shape == (384, 640, 3)
+    cl, cr = orc.ci_adcensus(L, R, 10, 30, 32, 16)
+    xl, al = orc.ca_cross(L, cl, 6, 20, 17, 8)
+    xr, ar = orc.ca_cross(R, cr, 6, 20, 17, 8)
+    dl, dr = orc.dc_wta(al, 16), orc.dc_wta(ar, 16)
+    assert 0.50 < (dl == -6).mean() < 0.54
+    assert 8.5 < xl.mean() < 9.5
+    ol, _ = orc.dr_dcc(dl, dr)
+    assert 0.13 < (ol > 0).mean() < 0.16
+    assert 1.0e6 < al.max() < 1.2e6
