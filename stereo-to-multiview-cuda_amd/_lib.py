@@ -74,6 +74,10 @@ def lib():
             raise RuntimeError(
                 "libstm_hip.so is missing (%s): build it with __graft_entry__.build() / make -C csrc; "
                 "there is no CPU fallback for the product path" % LIB_PATH)
+        # torch bundles its own libamdhip64.so.7; it must be in the process BEFORE this library is loaded so that
+        # both share ONE HIP runtime (same device context, torch streams valid for stm_set_stream).  Loading in the
+        # other order starts two runtimes and the second one finds "no ROCm-capable device".
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (args, res) in PROTOS.items():
             fn = getattr(l, name)
