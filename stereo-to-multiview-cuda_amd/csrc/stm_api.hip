@@ -490,7 +490,9 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
                         float ucd, float lcd, int usd, int lsd, int thresh_s, float thresh_h, int stages)
 {
     const int H = num_rows, W = num_cols, D = num_disp, N = num_views;
-    const size_t HW = (size_t)H * W, V = HW * D, IMG = HW * elem_sz;
+    const size_t HW = (size_t)H * W, IMG = HW * elem_sz;
+    const int NQ = (D + 3) / 4;
+    const size_t V = HW * NQ * 4; // volumes are kept quad-interleaved (float4 [NQ][H][W]) inside the frame
     Workspace::begin(3 * V * 4 + (size_t)(N + 2) * IMG + 64 * HW + (1u << 20));
 
     u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
@@ -498,7 +500,7 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
 
     float *cost = Workspace::get<float>(2 * V), *scratch = Workspace::get<float>(V);
     uint32_t *pk_l = Workspace::get<uint32_t>(HW), *pk_r = Workspace::get<uint32_t>(HW);
-    Vol cl = vol_slab(cost, HW), cr = vol_slab(cost + V, HW), sc = vol_slab(scratch, HW);
+    Vol cl = vol_quads(cost, HW), cr = vol_quads(cost + V, HW), sc = vol_quads(scratch, HW);
     core_ci(img_l, img_r, cl, cr, pk_l, pk_r, ad_coeff, census_coeff, D, zero_disp, H, W, elem_sz);
 
     Arms al = carve_arms(HW), ar = carve_arms(HW);

@@ -44,14 +44,45 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // A cost volume as the kernels see it: either the reference's table of plane pointers
 // (T1 in SURVEY 8a; `tab` is a DEVICE array of D device pointers) or a dense slab
 // [D][H][W] (`base` + d * plane_stride).  One branch per plane access, uniform per wave.
+// Third form, internal to the frame pipeline: QUADS = float4 [ceil(D/4)][H][W], the four hypotheses
+// 4q..4q+3 of a pixel interleaved in one 16-byte element (`plane_stride` counts float4 elements).
 struct Vol {
     float *const *tab;
     float *base;
     size_t plane_stride;
+    int quad;
     __device__ __forceinline__ float *plane(int d) const { return tab ? tab[d] : base + (size_t)d * plane_stride; }
 };
-static inline Vol vol_table(float **d_tab) { Vol v; v.tab = d_tab; v.base = nullptr; v.plane_stride = 0; return v; }
-static inline Vol vol_slab(float *base, size_t stride) { Vol v; v.tab = nullptr; v.base = base; v.plane_stride = stride; return v; }
+static inline Vol vol_table(float **d_tab) { Vol v; v.tab = d_tab; v.base = nullptr; v.plane_stride = 0; v.quad = 0; return v; }
+static inline Vol vol_slab(float *base, size_t stride) { Vol v; v.tab = nullptr; v.base = base; v.plane_stride = stride; v.quad = 0; return v; }
+static inline Vol vol_quads(float *base, size_t stride) { Vol v; v.tab = nullptr; v.base = base; v.plane_stride = stride; v.quad = 1; return v; }
+
+#ifdef __HIPCC__
+// A "quad" = the four hypotheses d0..d0+3 of one pixel.  PLANES layout: four dword accesses, one per
+// plane (each wave instruction is a contiguous 256-B row segment).  QUADS layout (internal to the frame
+// pipeline, Vol::quad): one 16-byte access.
+template <bool QUAD> __device__ __forceinline__ float4 load_quad(const Vol &v, int q, int D, size_t idx)
+{
+    if (QUAD) return ((const float4 *)v.base)[(size_t)q * v.plane_stride + idx];
+    const int d0 = q * 4;
+    float4 r;
+    r.x = v.plane(d0)[idx];
+    r.y = d0 + 1 < D ? v.plane(d0 + 1)[idx] : 0.f;
+    r.z = d0 + 2 < D ? v.plane(d0 + 2)[idx] : 0.f;
+    r.w = d0 + 3 < D ? v.plane(d0 + 3)[idx] : 0.f;
+    return r;
+}
+template <bool QUAD> __device__ __forceinline__ void store_quad(const Vol &v, int q, int D, size_t idx, float4 s)
+{
+    if (QUAD) { ((float4 *)v.base)[(size_t)q * v.plane_stride + idx] = s; return; }
+    const int d0 = q * 4;
+    v.plane(d0)[idx] = s.x;
+    if (d0 + 1 < D) v.plane(d0 + 1)[idx] = s.y;
+    if (d0 + 2 < D) v.plane(d0 + 2)[idx] = s.z;
+    if (d0 + 3 < D) v.plane(d0 + 3)[idx] = s.w;
+}
+
+#endif
 
 // ---- launchers (one per kernel family; definitions next to the kernels) -------------
 // cost init (stm_kernels_cost.hip)

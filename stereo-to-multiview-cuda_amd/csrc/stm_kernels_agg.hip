@@ -80,29 +80,46 @@ void launch_cross_arms(const uint32_t *packed, u8 *up, u8 *down, u8 *left, u8 *r
 }
 
 // ------------------------------------------------------------------ helpers
-__device__ __forceinline__ float4 load_quad(const Vol &v, int d0, int D, size_t idx)
+#define STM_ACC(s, v) { s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w; }
+
+// s += p[0] + p[S] + ... + p[(n-1)S], added strictly left to right (the reference's order,
+// d_ca_cross_sum.cu:284-289).  The four LDS reads of a group are issued back to back so their latency
+// overlaps; the adds stay a single dependent chain per hypothesis, which is what bit-exactness requires.
+template <int S> __device__ __forceinline__ float4 window_sum(const float4 *__restrict__ p, int n, float4 s)
 {
-    float4 r;
-    r.x = v.plane(d0)[idx];
-    r.y = d0 + 1 < D ? v.plane(d0 + 1)[idx] : 0.f;
-    r.z = d0 + 2 < D ? v.plane(d0 + 2)[idx] : 0.f;
-    r.w = d0 + 3 < D ? v.plane(d0 + 3)[idx] : 0.f;
-    return r;
+    while (n >= 4) {
+        float4 v0 = p[0], v1 = p[S], v2 = p[2 * S], v3 = p[3 * S];
+        p += 4 * S;
+        n -= 4;
+        STM_ACC(s, v0) STM_ACC(s, v1) STM_ACC(s, v2) STM_ACC(s, v3)
+    }
+    if (n & 2) {
+        float4 v0 = p[0], v1 = p[S];
+        p += 2 * S;
+        STM_ACC(s, v0) STM_ACC(s, v1)
+    }
+    if (n & 1) {
+        float4 v0 = p[0];
+        STM_ACC(s, v0)
+    }
+    return s;
 }
-__device__ __forceinline__ void store_quad(const Vol &v, int d0, int D, size_t idx, float4 s)
+
+// dynamic LDS above the 64 KiB default needs an explicit opt-in (gfx950 has 160 KiB per CU)
+static void allow_lds(const void *func, size_t bytes)
 {
-    v.plane(d0)[idx] = s.x;
-    if (d0 + 1 < D) v.plane(d0 + 1)[idx] = s.y;
-    if (d0 + 2 < D) v.plane(d0 + 2)[idx] = s.z;
-    if (d0 + 3 < D) v.plane(d0 + 3)[idx] = s.w;
+    if (bytes > 64 * 1024) STM_CHECK(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 
 // ------------------------------------------------------------------ horizontal pass
-constexpr int AH_T = 256;   // threads per block
-constexpr int AH_QPB = 4;   // disparity quads per block
+constexpr int AH_T = 256;    // threads per block
+constexpr int AH_QPB = 4;    // disparity quads per block (un-fused pass)
+constexpr int AH_MAXPPT = 16; // pixels per thread the register prefetch covers (W <= 4096)
 
-// LDS: float4 tile[W] + u16 arms[W]  (armL | armR << 8)
-template <bool WTA>
+// One block = one image row x `qpb` quads.  LDS: float4 tile[W] | u16 arms[W] (armL | armR << 8)
+// | (WTA only) best cost[W], best index[W].  While quad q is being summed out of LDS, quad q+1 is
+// already in flight from HBM into registers.
+template <bool QUAD, bool WTA>
 __global__ __launch_bounds__(AH_T) void stm_k_agg_h(Vol in, Vol out, const u8 *__restrict__ armL,
                                                     const u8 *__restrict__ armR, float *__restrict__ disp,
                                                     int D, int zd, int H, int W, int qpb)
@@ -110,54 +127,62 @@ __global__ __launch_bounds__(AH_T) void stm_k_agg_h(Vol in, Vol out, const u8 *_
     extern __shared__ float4 smem4[];
     float4 *tile = smem4;
     uint16_t *arms = (uint16_t *)(tile + W);
+    float *best_c = (float *)(arms + ((W + 1) & ~1));
+    int *best_d = (int *)(best_c + W);
     const int y = blockIdx.x, tid = threadIdx.x;
     const size_t row = (size_t)y * W;
     const int nq = (D + 3) >> 2;
     const int q0 = blockIdx.y * qpb, q1 = min(q0 + qpb, nq);
+    const int ppt = (W + AH_T - 1) / AH_T;
 
-    for (int x = tid; x < W; x += AH_T) arms[x] = (uint16_t)armL[row + x] | ((uint16_t)armR[row + x] << 8);
+    for (int x = tid; x < W; x += AH_T) {
+        arms[x] = (uint16_t)armL[row + x] | ((uint16_t)armR[row + x] << 8);
+        if (WTA) { best_c[x] = 3.402823466e+38f; best_d[x] = 0; }
+    }
 
-    // WTA state for up to 16 pixels per thread would need registers per pixel; instead WTA blocks
-    // (qpb == nq) keep the running minimum in LDS next to the tile: best cost + best index per pixel.
-    float *best_c = (float *)(arms + ((W + 1) & ~1));
-    int *best_d = (int *)(best_c + W);
-    if (WTA)
-        for (int x = tid; x < W; x += AH_T) { best_c[x] = 3.402823466e+38f; best_d[x] = 0; }
-
+    float4 pre[AH_MAXPPT];
+#pragma unroll
+    for (int i = 0; i < AH_MAXPPT; ++i) {
+        int x = tid + i * AH_T;
+        if (i < ppt && x < W) pre[i] = load_quad<QUAD>(in, q0, D, row + x);
+    }
     for (int q = q0; q < q1; ++q) {
-        const int d0 = q * 4;
-        __syncthreads(); // previous quad's readers are done with the tile (and arms are visible)
-        for (int x = tid; x < W; x += AH_T) tile[x] = load_quad(in, d0, D, row + x);
+        __syncthreads(); // previous quad's readers are done with the tile (first time: arms visible)
+#pragma unroll
+        for (int i = 0; i < AH_MAXPPT; ++i) {
+            int x = tid + i * AH_T;
+            if (i < ppt && x < W) tile[x] = pre[i];
+        }
         __syncthreads();
+        if (q + 1 < q1) {
+#pragma unroll
+            for (int i = 0; i < AH_MAXPPT; ++i) {
+                int x = tid + i * AH_T;
+                if (i < ppt && x < W) pre[i] = load_quad<QUAD>(in, q + 1, D, row + x);
+            }
+        }
+        const int d0 = q * 4;
         for (int x = tid; x < W; x += AH_T) {
             uint32_t ar = arms[x];
-            int a = x - (int)(ar & 0xff), b = x + (int)(ar >> 8);
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int k = a; k < b; ++k) {
-                float4 v = tile[k];
-                s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
-            }
+            int aL = (int)(ar & 0xff), n = aL + (int)(ar >> 8); // window [x - armL, x + armR)
+            float4 s = window_sum<1>(tile + (x - aL), n, make_float4(0.f, 0.f, 0.f, 0.f));
             if (WTA) {
                 // first strictly-lowest cost wins, ascending d (d_dc_wta.cu:19-34)
-                float bc = best_c[x]; int bd = best_d[x];
+                float bc = best_c[x];
+                int bd = best_d[x];
                 if (bc > s.x) { bc = s.x; bd = d0; }
                 if (d0 + 1 < D && bc > s.y) { bc = s.y; bd = d0 + 1; }
                 if (d0 + 2 < D && bc > s.z) { bc = s.z; bd = d0 + 2; }
                 if (d0 + 3 < D && bc > s.w) { bc = s.w; bd = d0 + 3; }
-                best_c[x] = bc; best_d[x] = bd;
+                best_c[x] = bc;
+                best_d[x] = bd;
             } else {
-                store_quad(out, d0, D, row + x, s);
+                store_quad<QUAD>(out, q, D, row + x, s);
             }
         }
     }
     if (WTA)
-        for (int x = tid; x < W; x += AH_T) disp[row + x] = (float)best_d[x] - (float)zd; // own pixels only: no barrier needed
-}
-
-// dynamic LDS above the 64 KiB default needs an explicit opt-in (gfx950 has 160 KiB per CU)
-static void allow_lds(const void *func, size_t bytes)
-{
-    if (bytes > 64 * 1024) STM_CHECK(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        for (int x = tid; x < W; x += AH_T) disp[row + x] = (float)best_d[x] - (float)zd; // own pixels only
 }
 
 static size_t agg_h_smem(int W, bool wta)
@@ -167,14 +192,23 @@ static size_t agg_h_smem(int W, bool wta)
     return s;
 }
 
+template <bool QUAD, bool WTA>
+static void launch_agg_h_t(Vol in, Vol out, const u8 *armL, const u8 *armR, float *disp, int D, int zd, int H, int W, int qpb)
+{
+    if (W > AH_T * AH_MAXPPT) fail("aggregation: num_cols > 4096 is not supported by the row-tile kernel", "W", __FILE__, __LINE__);
+    int nq = (D + 3) / 4;
+    size_t smem = agg_h_smem(W, WTA);
+    allow_lds((const void *)stm_k_agg_h<QUAD, WTA>, smem);
+    hipLaunchKernelGGL((stm_k_agg_h<QUAD, WTA>), dim3(H, cdiv(nq, qpb)), dim3(AH_T), smem, stream(), in, out, armL, armR, disp,
+                       D, zd, H, W, qpb);
+    STM_CHECK_LAUNCH();
+}
+
 void launch_agg_h(Vol in, Vol out, const u8 *armL, const u8 *armR, int D, int H, int W)
 {
-    int nq = (D + 3) / 4;
-    allow_lds((const void *)stm_k_agg_h<false>, agg_h_smem(W, false));
     ProfScope p("agg_h");
-    hipLaunchKernelGGL(stm_k_agg_h<false>, dim3(H, cdiv(nq, AH_QPB)), dim3(AH_T), agg_h_smem(W, false), stream(), in, out,
-                       armL, armR, (float *)nullptr, D, 0, H, W, AH_QPB);
-    STM_CHECK_LAUNCH();
+    if (in.quad) launch_agg_h_t<true, false>(in, out, armL, armR, nullptr, D, 0, H, W, AH_QPB);
+    else launch_agg_h_t<false, false>(in, out, armL, armR, nullptr, D, 0, H, W, AH_QPB);
 }
 
 // last horizontal pass fused with WTA: the aggregated volume is consumed in LDS and never written
@@ -182,20 +216,21 @@ void launch_agg_h_wta(Vol in, const u8 *armL, const u8 *armR, float *disp, int D
 {
     int nq = (D + 3) / 4;
     Vol none = vol_slab(nullptr, 0);
-    allow_lds((const void *)stm_k_agg_h<true>, agg_h_smem(W, true));
     ProfScope p("agg_hw");
-    hipLaunchKernelGGL(stm_k_agg_h<true>, dim3(H, 1), dim3(AH_T), agg_h_smem(W, true), stream(), in, none, armL, armR,
-                       disp, D, zd, H, W, nq);
-    STM_CHECK_LAUNCH();
+    if (in.quad) launch_agg_h_t<true, true>(in, none, armL, armR, disp, D, zd, H, W, nq);
+    else launch_agg_h_t<false, true>(in, none, armL, armR, disp, D, zd, H, W, nq);
 }
 
 // ------------------------------------------------------------------ vertical pass
-constexpr int AV_TX = 32;   // columns per block
-constexpr int AV_TY = 8;    // thread rows per block (256 threads)
-constexpr int AV_CH = 8;    // output rows per step (= AV_TY: one row per thread row)
-static int av_band(int H) { int b = (cdiv(H, 4) + AV_CH - 1) / AV_CH * AV_CH; return b < AV_CH ? AV_CH : b; } // output rows per block
+constexpr int AV_TX = 32; // columns per block
+constexpr int AV_TY = 8;  // thread rows per block (256 threads) == output rows per step
 
-// ring[R][AV_TX] of float4, R = power of two >= 2*usd + AV_CH.  Row r of the plane lives in slot r & (R-1).
+// One block = AV_TX columns x a band of rows x one quad.  Rows stream top to bottom through an LDS ring
+// of R = roundup(2 usd, AV_TY) + AV_TY rows (row r lives in slot r % R; R is a multiple of AV_TY and every
+// band starts at a multiple of AV_TY, so slots advance without any division).  A window wraps around the
+// ring at most once and is summed as two linear segments.  The rows of the next step are fetched from HBM
+// into registers while the current step is summed.
+template <bool QUAD>
 __global__ __launch_bounds__(AV_TX *AV_TY) void stm_k_agg_v(Vol in, Vol out, const u8 *__restrict__ armU,
                                                             const u8 *__restrict__ armD, int D, int H, int W, int usd,
                                                             int R, int band)
@@ -204,44 +239,84 @@ __global__ __launch_bounds__(AV_TX *AV_TY) void stm_k_agg_v(Vol in, Vol out, con
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int x = blockIdx.x * AV_TX + tx;
     const int yb0 = blockIdx.y * band, yb1 = min(yb0 + band, H);
-    const int d0 = blockIdx.z * 4;
-    const int mask = R - 1;
+    const int q = blockIdx.z;
     const bool xin = x < W;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    int loaded = max(yb0 - usd, 0); // rows [max(yb0-usd,0), loaded) are in the ring
-    for (int y0 = yb0; y0 < yb1; y0 += AV_CH) {
-        // rows needed by this step: up to y0 + AV_CH - 1 + usd - 1 (window is half-open at the bottom)
-        const int need = min(y0 + AV_CH + usd - 1, H);
+    // initial fill: rows [first, yb0 + usd) of the first step's needs minus its own AV_TY-row prefetch below
+    const int first = max(yb0 - usd, 0);
+    int slot_first = first % R;
+    int loaded = min(yb0 + usd - 1, H); // rows [first, loaded) go in now; the per-step prefetch adds AV_TY rows
+    if (loaded < first) loaded = first;
+    for (int r = first + ty; r < loaded; r += AV_TY) {
+        int s = slot_first + (r - first);
+        if (s >= R) s -= R;
+        ring[s * AV_TX + tx] = xin ? load_quad<QUAD>(in, q, D, (size_t)r * W + x) : zero4;
+    }
+    int slot_loaded = slot_first + (loaded - first);
+    if (slot_loaded >= R) slot_loaded -= R;
+    int slot_y0 = yb0 % R;
+
+    // prefetch for the first step: rows [loaded, loaded + AV_TY)
+    float4 pre = zero4;
+    {
+        int r = loaded + ty;
+        if (xin && r < H) pre = load_quad<QUAD>(in, q, D, (size_t)r * W + x);
+    }
+    for (int y0 = yb0; y0 < yb1; y0 += AV_TY) {
         __syncthreads(); // everyone finished the previous step before its oldest rows are overwritten
-        for (int r = loaded + ty; r < need; r += AV_TY)
-            ring[(r & mask) * AV_TX + tx] = xin ? load_quad(in, d0, D, (size_t)r * W + x) : make_float4(0, 0, 0, 0);
-        loaded = max(loaded, need);
+        {
+            int r = loaded + ty;
+            int s = slot_loaded + ty;
+            if (s >= R) s -= R;
+            if (r < H) ring[s * AV_TX + tx] = pre;
+        }
+        loaded += AV_TY;
+        slot_loaded += AV_TY;
+        if (slot_loaded >= R) slot_loaded -= R;
         __syncthreads();
+        {
+            int r = loaded + ty; // next step's row, in flight during this step's sums
+            if (xin && r < H && y0 + AV_TY < yb1) pre = load_quad<QUAD>(in, q, D, (size_t)r * W + x);
+        }
         const int y = y0 + ty;
         if (xin && y < yb1) {
             const size_t p = (size_t)y * W + x;
-            int a = y - (int)armU[p], b = y + (int)armD[p];
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int k = a; k < b; ++k) {
-                float4 v = ring[(k & mask) * AV_TX + tx];
-                s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
-            }
-            store_quad(out, d0, D, p, s);
+            const int aU = (int)armU[p], n = aU + (int)armD[p]; // window [y - armU, y + armD)
+            int sa = slot_y0 + ty - aU;
+            if (sa < 0) sa += R;
+            const int n1 = min(n, R - sa);
+            float4 s = window_sum<AV_TX>(ring + sa * AV_TX + tx, n1, zero4);
+            s = window_sum<AV_TX>(ring + tx, n - n1, s);
+            store_quad<QUAD>(out, q, D, p, s);
         }
+        slot_y0 += AV_TY;
+        if (slot_y0 >= R) slot_y0 -= R;
     }
+}
+
+static int av_band(int H)
+{
+    int b = (cdiv(H, 2) + AV_TY - 1) / AV_TY * AV_TY; // two bands: +usd/H halo re-reads, twice the blocks
+    return b < AV_TY ? AV_TY : b;
 }
 
 void launch_agg_v(Vol in, Vol out, const u8 *armU, const u8 *armD, int D, int H, int W, int usd)
 {
     int nq = (D + 3) / 4;
-    int R = 16;
-    while (R < 2 * usd + AV_CH) R <<= 1;
+    int R = (2 * usd + AV_TY - 1) / AV_TY * AV_TY + AV_TY;
     size_t smem = (size_t)R * AV_TX * 16;
     int band = av_band(H);
-    allow_lds((const void *)stm_k_agg_v, smem);
     ProfScope p("agg_v");
-    hipLaunchKernelGGL(stm_k_agg_v, dim3(cdiv(W, AV_TX), cdiv(H, band), nq), dim3(AV_TX, AV_TY), smem, stream(), in,
-                       out, armU, armD, D, H, W, usd, R, band);
+    if (in.quad) {
+        allow_lds((const void *)stm_k_agg_v<true>, smem);
+        hipLaunchKernelGGL(stm_k_agg_v<true>, dim3(cdiv(W, AV_TX), cdiv(H, band), nq), dim3(AV_TX, AV_TY), smem, stream(),
+                           in, out, armU, armD, D, H, W, usd, R, band);
+    } else {
+        allow_lds((const void *)stm_k_agg_v<false>, smem);
+        hipLaunchKernelGGL(stm_k_agg_v<false>, dim3(cdiv(W, AV_TX), cdiv(H, band), nq), dim3(AV_TX, AV_TY), smem, stream(),
+                           in, out, armU, armD, D, H, W, usd, R, band);
+    }
     STM_CHECK_LAUNCH();
 }
 
@@ -252,9 +327,19 @@ __global__ __launch_bounds__(256) void stm_k_wta(Vol cost, float *__restrict__ d
     if (p >= HW) return;
     float lowest = 3.402823466e+38f;
     int best = 0;
-    for (int d = 0; d < D; ++d) {
-        float c = cost.plane(d)[p];
-        if (lowest > c) { lowest = c; best = d; }
+    if (cost.quad) {
+        for (int q = 0; q * 4 < D; ++q) {
+            float4 c = ((const float4 *)cost.base)[(size_t)q * cost.plane_stride + p];
+            if (lowest > c.x) { lowest = c.x; best = q * 4; }
+            if (q * 4 + 1 < D && lowest > c.y) { lowest = c.y; best = q * 4 + 1; }
+            if (q * 4 + 2 < D && lowest > c.z) { lowest = c.z; best = q * 4 + 2; }
+            if (q * 4 + 3 < D && lowest > c.w) { lowest = c.w; best = q * 4 + 3; }
+        }
+    } else {
+        for (int d = 0; d < D; ++d) {
+            float c = cost.plane(d)[p];
+            if (lowest > c) { lowest = c; best = d; }
+        }
     }
     disp[p] = (float)best - (float)zd;
 }

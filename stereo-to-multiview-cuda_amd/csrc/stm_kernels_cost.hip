@@ -101,6 +101,7 @@ __device__ __forceinline__ int hamdist_ref(uint32_t a, uint32_t b)
 constexpr int CI_TX = 256;
 // one block = CI_TX pixels of one row, all D hypotheses.
 // left  cost: L(x) vs R(clamp(x + o)), right cost: R(x) vs L(clamp(x - o)), o = d - zd  (A-Q6, clean A-Q7)
+template <bool QUAD>
 __global__ __launch_bounds__(CI_TX) void stm_k_cost_init(const uint32_t *__restrict__ pk_l, const uint32_t *__restrict__ pk_r,
                                                          const uint32_t *__restrict__ cen_l, const uint32_t *__restrict__ cen_r,
                                                          Vol cost_l, Vol cost_r,
@@ -130,20 +131,30 @@ __global__ __launch_bounds__(CI_TX) void stm_k_cost_init(const uint32_t *__restr
     if (x >= W) return;
     int c = tid + pad;
     uint32_t pl0 = s_pl[c], pr0 = s_pr[c], cl0 = s_cl[c], cr0 = s_cr[c];
-    for (int d = 0; d < D; ++d) {
-        int o = d - zd;
-        // clamp-to-edge is in GLOBAL coordinates; the tile was filled with clamped pixels, so a plain
-        // tile offset reproduces it as long as |o| <= pad (pad = max(zd, D-1-zd)).
-        uint32_t pr1 = s_pr[c + o], cr1 = s_cr[c + o];
-        uint32_t pl1 = s_pl[c - o], cl1 = s_cl[c - o];
-        int ad_l = (int)__builtin_amdgcn_sad_u8(pl0, pr1, 0u);
-        int ad_r = (int)__builtin_amdgcn_sad_u8(pr0, pl1, 0u);
-        int h_l = hamdist_ref(cl0, cr1);
-        int h_r = hamdist_ref(cr0, cl1);
-        float vl = s_lut_ad[ad_l] + s_lut_c[h_l];
-        float vr = s_lut_ad[ad_r] + s_lut_c[h_r];
-        cost_l.plane(d)[row + x] = vl;
-        cost_r.plane(d)[row + x] = vr;
+    const int nq = (D + 3) >> 2;
+    for (int q = 0; q < nq; ++q) {
+        float vl[4], vr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = q * 4 + j;
+            vl[j] = 0.f;
+            vr[j] = 0.f;
+            if (d < D) {
+                const int o = d - zd;
+                // clamp-to-edge is in GLOBAL coordinates; the tile was filled with clamped pixels, so a plain
+                // tile offset reproduces it as long as |o| <= pad (pad = max(zd, D-1-zd)).
+                uint32_t pr1 = s_pr[c + o], cr1 = s_cr[c + o];
+                uint32_t pl1 = s_pl[c - o], cl1 = s_cl[c - o];
+                int ad_l = (int)__builtin_amdgcn_sad_u8(pl0, pr1, 0u);
+                int ad_r = (int)__builtin_amdgcn_sad_u8(pr0, pl1, 0u);
+                int h_l = hamdist_ref(cl0, cr1);
+                int h_r = hamdist_ref(cr0, cl1);
+                vl[j] = s_lut_ad[ad_l] + s_lut_c[h_l];
+                vr[j] = s_lut_ad[ad_r] + s_lut_c[h_r];
+            }
+        }
+        store_quad<QUAD>(cost_l, q, D, row + x, make_float4(vl[0], vl[1], vl[2], vl[3]));
+        store_quad<QUAD>(cost_r, q, D, row + x, make_float4(vr[0], vr[1], vr[2], vr[3]));
     }
 }
 
@@ -155,8 +166,12 @@ void launch_cost_init(const uint32_t *pk_l, const uint32_t *pk_r, const uint32_t
     if (pad < 0) pad = 0;
     size_t smem = (size_t)(4 * (CI_TX + 2 * pad) + 768 + 72) * 4;
     ProfScope p("cost_init");
-    hipLaunchKernelGGL(stm_k_cost_init, dim3(cdiv(W, CI_TX), H), dim3(CI_TX), smem, stream(),
-                       pk_l, pk_r, cen_l, cen_r, cost_l, cost_r, lut_ad, lut_census, D, zd, H, W, pad);
+    if (cost_l.quad)
+        hipLaunchKernelGGL(stm_k_cost_init<true>, dim3(cdiv(W, CI_TX), H), dim3(CI_TX), smem, stream(),
+                           pk_l, pk_r, cen_l, cen_r, cost_l, cost_r, lut_ad, lut_census, D, zd, H, W, pad);
+    else
+        hipLaunchKernelGGL(stm_k_cost_init<false>, dim3(cdiv(W, CI_TX), H), dim3(CI_TX), smem, stream(),
+                           pk_l, pk_r, cen_l, cen_r, cost_l, cost_r, lut_ad, lut_census, D, zd, H, W, pad);
     STM_CHECK_LAUNCH();
 }
 
