@@ -294,22 +294,26 @@ void stm_d_dr_irv(float *d_disp, unsigned char *d_outliers, unsigned char **d_cr
                   int num_rows, int num_cols, int num_disp, int zero_disp, int usd, int iterations)
 {
     size_t HW = (size_t)num_rows * num_cols;
-    Workspace::begin(8 * HW + 1024);
+    Workspace::begin(12 * HW + 4096);
     Arms a = arms_from_table(d_cross);
     int *md = Workspace::get<int>(HW), *rel = Workspace::get<int>(HW);
-    launch_irv(d_disp, d_outliers, a.up, a.down, a.left, a.right, md, rel, thresh_s, thresh_h, num_rows, num_cols, num_disp,
+    uint32_t *lst = Workspace::get<uint32_t>(HW);
+    int *cnt = Workspace::get<int>(1);
+    launch_irv(d_disp, d_outliers, a.up, a.down, a.left, a.right, md, rel, lst, cnt, thresh_s, thresh_h, num_rows, num_cols, num_disp,
                zero_disp, usd, iterations, true);
 }
 void stm_dr_irv(float *disp, unsigned char *outliers, unsigned char **cross, int thresh_s, float thresh_h, int num_rows,
                 int num_cols, int num_disp, int zero_disp, int usd, int iterations)
 {
     size_t HW = (size_t)num_rows * num_cols;
-    Workspace::begin(20 * HW + 8192);
+    Workspace::begin(24 * HW + 8192);
     float *d = up(disp, HW);
     u8 *o = up(outliers, HW);
     Arms a{up(cross[0], HW), up(cross[1], HW), up(cross[2], HW), up(cross[3], HW)};
     int *md = Workspace::get<int>(HW), *rel = Workspace::get<int>(HW);
-    launch_irv(d, o, a.up, a.down, a.left, a.right, md, rel, thresh_s, thresh_h, num_rows, num_cols, num_disp, zero_disp, usd,
+    uint32_t *lst = Workspace::get<uint32_t>(HW);
+    int *cnt = Workspace::get<int>(1);
+    launch_irv(d, o, a.up, a.down, a.left, a.right, md, rel, lst, cnt, thresh_s, thresh_h, num_rows, num_cols, num_disp, zero_disp, usd,
                iterations, false);
     down(disp, d, HW); down(outliers, o, HW);
     sync();
@@ -515,8 +519,10 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
     STM_CHECK(hipMemsetAsync(outl_r, 0, HW, stream()));
     launch_dcc(outl_l, outl_r, d_disp_l, d_disp_r, hit_l, hit_r, H, W);
     int *md = Workspace::get<int>(HW), *rel = Workspace::get<int>(HW);
-    launch_irv(d_disp_l, outl_l, al.up, al.down, al.left, al.right, md, rel, thresh_s, thresh_h, H, W, D, zero_disp, usd, 5, true); // :147
-    launch_irv(d_disp_r, outl_r, ar.up, ar.down, ar.left, ar.right, md, rel, thresh_s, thresh_h, H, W, D, zero_disp, usd, 5, true); // :148
+    uint32_t *lst = Workspace::get<uint32_t>(HW);
+    int *cnt = Workspace::get<int>(1);
+    launch_irv(d_disp_l, outl_l, al.up, al.down, al.left, al.right, md, rel, lst, cnt, thresh_s, thresh_h, H, W, D, zero_disp, usd, 5, true); // :147
+    launch_irv(d_disp_r, outl_r, ar.up, ar.down, ar.left, ar.right, md, rel, lst, cnt, thresh_s, thresh_h, H, W, D, zero_disp, usd, 5, true); // :148
     core_bilateral(d_disp_l, 7, 5.0f, 10.0f, H, W, D); // :150
     core_bilateral(d_disp_r, 7, 5.0f, 10.0f, H, W, D); // :151
     if (stages < 3) return;

@@ -101,7 +101,7 @@ void launch_wta(Vol cost, float *disp, int D, int zd, int H, int W);
 // refinement (stm_kernels_refine.hip)
 void launch_dcc(u8 *out_l, u8 *out_r, const float *disp_l, const float *disp_r, u8 *hit_l, u8 *hit_r, int H, int W);
 void launch_irv(float *disp, u8 *outl, const u8 *up, const u8 *down, const u8 *left, const u8 *right,
-                int *max_disp, int *reliable, int thresh_s, float thresh_h,
+                int *max_disp, int *reliable, uint32_t *list, int *counter, int thresh_s, float thresh_h,
                 int H, int W, int D, int zd, int usd, int iterations, bool device_flavour);
 void launch_bilateral(const float *in, float *out, const float *spatial, const float *color,
                       int radius, int H, int W, int D);

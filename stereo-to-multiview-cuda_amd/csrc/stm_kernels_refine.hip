@@ -55,44 +55,97 @@ void launch_dcc(u8 *out_l, u8 *out_r, const float *disp_l, const float *disp_r, 
 }
 
 // ------------------------------------------------------------------ iterative region voting
-// One thread per pixel; only outlier pixels vote.  The histogram has max(D,65) bins (the reference's
-// fixed int[65] overflows for D > 65, SURVEY A-Q17 ii) of u16 per thread in LDS, laid out
-// [bin][thread] so a wave's increments hit 64 distinct addresses.
-constexpr int IRV_T = 64;
-__global__ __launch_bounds__(IRV_T) void stm_k_irv_vote(const float *__restrict__ disp, const u8 *__restrict__ outl,
-                                                        const u8 *__restrict__ aU, const u8 *__restrict__ aD,
-                                                        const u8 *__restrict__ aL, const u8 *__restrict__ aR,
-                                                        int *__restrict__ max_disp, int *__restrict__ reliable,
-                                                        int H, int W, int nb, int zd, int usd)
+// Outliers are few (2 % of a synthetic frame, ~15 % of a real one, fewer every iteration) but each one
+// walks a cross region of ~600 pixels, so a thread per pixel leaves most lanes idle and a thread per
+// outlier leaves most of the CHIP idle.  Here: (1) a compaction kernel lists the outlier pixels;
+// (2) a persistent grid of waves pulls outliers off the list, one WAVE per outlier: each half-wave takes
+// one row of the cross region (32 pixels per step, coalesced), equal bins are merged with ballots and
+// counted in a per-wave LDS histogram, and the winner is a wave-wide max over (count, -bin).
+// Every outlier's result is independent of the list order, so the atomic compaction is deterministic
+// where it matters.  Histogram: max(D,65) bins (the reference's int[65] overflows for D > 65, A-Q17 ii).
+__global__ __launch_bounds__(256) void stm_k_irv_compact(const u8 *__restrict__ outl, uint32_t *__restrict__ list,
+                                                         int *__restrict__ count, uint32_t HW)
 {
-    extern __shared__ uint16_t hist[]; // [nb][IRV_T]
-    int tx = threadIdx.x;
-    int gx = blockIdx.x * IRV_T + tx, gy = blockIdx.y;
-    if (gx >= W) return;
-    size_t p = (size_t)gy * W + gx;
-    if (outl[p] == 0) return;
-    for (int i = 0; i < nb; ++i) hist[i * IRV_T + tx] = 0;
-    int cu = aU[p], cd = aD[p];
-    if (cu > usd) cu = usd; // d_dr_irv.cu:179-180
-    int max_bin = 0, max_d = (int)disp[p], total = 0;
-    for (int y = -cu; y <= cd; ++y) { // inclusive window (SURVEY A-Q17 iii)
-        size_t q = (size_t)(gy + y) * W + gx;
-        int cl = aL[q], cr = aR[q];
-        for (int x = -cl; x <= cr; ++x) {
-            size_t s = q + x; // arms never leave the image, so the reference's clamp is the identity
-            if (outl[s] == 0) {
-                int b = (int)disp[s] + zd;
-                if (b >= 0 && b < nb) hist[b * IRV_T + tx]++;
-                total++;
+    uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p < HW && outl[p] != 0) list[atomicAdd(count, 1)] = p;
+}
+
+constexpr int IV_WAVES = 4;   // waves per block
+constexpr int IV_BLOCKS = 2048; // persistent grid
+__global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(const float *__restrict__ disp, const u8 *__restrict__ outl,
+                                                                const u8 *__restrict__ aU, const u8 *__restrict__ aD,
+                                                                const u8 *__restrict__ aL, const u8 *__restrict__ aR,
+                                                                const uint32_t *__restrict__ list, const int *__restrict__ count,
+                                                                int *__restrict__ max_disp, int *__restrict__ reliable,
+                                                                int H, int W, int nb, int zd, int usd)
+{
+    extern __shared__ uint32_t hist_all[]; // [IV_WAVES][nb]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, l = lane & 31;
+    uint32_t *hist = hist_all + wave * nb;
+    const int n = *count;
+    for (int i = blockIdx.x * IV_WAVES + wave; i < n; i += gridDim.x * IV_WAVES) {
+        const uint32_t p = list[i];
+        const int gy = (int)(p / (uint32_t)W), gx = (int)(p - (uint32_t)gy * (uint32_t)W);
+        for (int b = lane; b < nb; b += 64) hist[b] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int cu = aU[p], cd = aD[p];
+        if (cu > usd) cu = usd; // d_dr_irv.cu:179-180
+        cu = min(cu, gy);         // arms built by ca_cross never leave the image; these two clamps only keep a
+        cd = min(cd, H - 1 - gy); // caller who passes inconsistent arms from reading outside the planes
+        int total = 0;
+        // rows gy-cu .. gy+cd inclusive, in each row x-armL(row) .. x+armR(row) inclusive (SURVEY A-Q17 iii)
+        for (int r = -cu; r <= cd; r += 2) {
+            const int rr = r + half;
+            const bool rowok = rr <= cd;
+            const size_t q = (size_t)(gy + (rowok ? rr : 0)) * W + gx;
+            const int cl = rowok ? (int)aL[q] : 0;
+            const int width = rowok ? cl + (int)aR[q] + 1 : 0;
+            const int wmax = max(__shfl(width, 0), __shfl(width, 32));
+            for (int c0 = 0; c0 < wmax; c0 += 32) {
+                const int xo = c0 + l;
+                int code = -1; // -1: no vote (outside the row segment, or an outlier itself)
+                if (xo < width && gx - cl + xo >= 0 && gx - cl + xo < W) {
+                    const size_t s = q - cl + xo;
+                    if (outl[s] == 0) {
+                        const int b = (int)disp[s] + zd; // d_dr_irv.cu:200-201
+                        code = (b >= 0 && b < nb) ? b : -2; // -2: reliable, but its bin is out of range
+                    }
+                }
+                total += __popcll(__ballot(code != -1));
+                unsigned long long act = __ballot(code >= 0);
+                while (act) {
+                    const int leader = __ffsll((long long)act) - 1;
+                    const int b0 = __shfl(code, leader);
+                    const unsigned long long m = __ballot(code == b0);
+                    if (lane == leader) atomicAdd(&hist[b0], (uint32_t)__popcll(m));
+                    act &= ~m;
+                }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // first bin with the strictly largest count (d_dr_irv.cu:206-215): max over (count, -bin)
+        uint32_t key = 0;
+        for (int b = lane; b < nb; b += 64) {
+            uint32_t c = hist[b];
+            uint32_t k = (c << 16) | (uint32_t)(0xFFFF - b);
+            if (c != 0 && k > key) key = k;
+        }
+        for (int o = 32; o >= 1; o >>= 1) {
+            uint32_t other = (uint32_t)__shfl_xor((int)key, o);
+            if (other > key) key = other;
+        }
+        if (lane == 0) {
+            int max_d = (int)disp[p]; // default: own disparity (d_dr_irv.cu:182)
+            if (key != 0) max_d = (0xFFFF - (int)(key & 0xFFFF)) - zd;
+            max_disp[p] = max_d;
+            reliable[p] = total;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    for (int i = 0; i < nb; ++i) {
-        int c = hist[i * IRV_T + tx];
-        if (max_bin < c) { max_bin = c; max_d = i - zd; }
-    }
-    max_disp[p] = max_d;
-    reliable[p] = total;
 }
 
 __global__ __launch_bounds__(256) void stm_k_irv_apply(float *__restrict__ disp, u8 *__restrict__ outl,
@@ -113,16 +166,20 @@ __global__ __launch_bounds__(256) void stm_k_irv_apply(float *__restrict__ disp,
 }
 
 void launch_irv(float *disp, u8 *outl, const u8 *up, const u8 *down, const u8 *left, const u8 *right, int *max_disp,
-                int *reliable, int thresh_s, float thresh_h, int H, int W, int D, int zd, int usd, int iterations,
-                bool device_flavour)
+                int *reliable, uint32_t *list, int *counter, int thresh_s, float thresh_h, int H, int W, int D, int zd,
+                int usd, int iterations, bool device_flavour)
 {
     size_t HW = (size_t)H * W;
     int nb = D > 65 ? D : 65;
-    size_t smem = (size_t)nb * IRV_T * 2;
+    size_t smem = (size_t)nb * IV_WAVES * 4;
     auto vote = [&]() {
         ProfScope p("irv_vote");
-        hipLaunchKernelGGL(stm_k_irv_vote, dim3(cdiv(W, IRV_T), H), dim3(IRV_T), smem, stream(), disp, outl, up, down, left,
-                           right, max_disp, reliable, H, W, nb, zd, usd);
+        STM_CHECK(hipMemsetAsync(counter, 0, sizeof(int), stream()));
+        hipLaunchKernelGGL(stm_k_irv_compact, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream(), outl, list, counter,
+                           (uint32_t)HW);
+        STM_CHECK_LAUNCH();
+        hipLaunchKernelGGL(stm_k_irv_vote, dim3(IV_BLOCKS), dim3(64 * IV_WAVES), smem, stream(), disp, outl, up, down, left,
+                           right, list, counter, max_disp, reliable, H, W, nb, zd, usd);
         STM_CHECK_LAUNCH();
     };
     auto apply = [&]() {
