@@ -63,15 +63,55 @@ void launch_dcc(u8 *out_l, u8 *out_r, const float *disp_l, const float *disp_r, 
 // counted in a per-wave LDS histogram, and the winner is a wave-wide max over (count, -bin).
 // Every outlier's result is independent of the list order, so the atomic compaction is deterministic
 // where it matters.  Histogram: max(D,65) bins (the reference's int[65] overflows for D > 65, A-Q17 ii).
+// four pixels per thread (one dword of the u8 outlier map); one global atomic per WAVE that holds any outlier
 __global__ __launch_bounds__(256) void stm_k_irv_compact(const u8 *__restrict__ outl, uint32_t *__restrict__ list,
                                                          int *__restrict__ count, uint32_t HW)
 {
-    uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p < HW && outl[p] != 0) list[atomicAdd(count, 1)] = p;
+    const uint32_t p = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    const int lane = threadIdx.x & 63;
+    uint32_t w = 0;
+    if (p < HW) {
+        if (p + 4 <= HW && (((uintptr_t)outl) & 3) == 0) w = *(const uint32_t *)(outl + p);
+        else
+            for (uint32_t j = 0; j < 4 && p + j < HW; ++j) w |= (uint32_t)outl[p + j] << (8 * j);
+    }
+    int c = ((w & 0xff) != 0) + ((w & 0xff00) != 0) + ((w & 0xff0000) != 0) + ((w & 0xff000000u) != 0);
+    if (__ballot(c != 0) == 0) return; // wave-uniform
+    int incl = c; // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const int wave_total = __shfl(incl, 63);
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, wave_total);
+    base = __shfl(base, 0);
+    int k = base + incl - c;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j)
+        if ((w >> (8 * j)) & 0xff) list[k++] = p + j;
 }
 
-constexpr int IV_WAVES = 4;   // waves per block
+constexpr int IV_WAVES = 4;     // waves per block
 constexpr int IV_BLOCKS = 2048; // persistent grid
+constexpr int IV_U = 4;         // row pairs whose loads are in flight together
+
+// value held by lane (j & 63) of v0 (j < 64) or v1 (j >= 64), for a wave-uniform j
+__device__ __forceinline__ int irv_row_value(int v0, int v1, int j)
+{
+    return j < 64 ? __builtin_amdgcn_readlane(v0, j) : __builtin_amdgcn_readlane(v1, j - 64);
+}
+
+// one LDS atomic per voting lane: equal bins serialise inside the LDS atomic unit (<= 64 cycles), which beats a
+// ballot-merge loop whenever a step sees more than a couple of distinct disparities -- and outliers sit exactly
+// where the disparity map is noisy
+__device__ __forceinline__ void irv_tally(int code, int lane, uint32_t *hist, int &total)
+{
+    total += __popcll(__ballot(code != -1));
+    if (code >= 0) atomicAdd(&hist[code], 1u);
+}
+
 __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(const float *__restrict__ disp, const u8 *__restrict__ outl,
                                                                 const u8 *__restrict__ aU, const u8 *__restrict__ aD,
                                                                 const u8 *__restrict__ aL, const u8 *__restrict__ aR,
@@ -91,36 +131,77 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(const float *__r
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         int cu = aU[p], cd = aD[p];
-        if (cu > usd) cu = usd; // d_dr_irv.cu:179-180
+        if (cu > usd) cu = usd;   // d_dr_irv.cu:179-180
         cu = min(cu, gy);         // arms built by ca_cross never leave the image; these two clamps only keep a
         cd = min(cd, H - 1 - gy); // caller who passes inconsistent arms from reading outside the planes
+        const int nrows = cu + cd + 1; // rows gy-cu .. gy+cd inclusive (SURVEY A-Q17 iii), at most 2*255+1
+        const int y_top = gy - cu;
         int total = 0;
-        // rows gy-cu .. gy+cd inclusive, in each row x-armL(row) .. x+armR(row) inclusive (SURVEY A-Q17 iii)
-        for (int r = -cu; r <= cd; r += 2) {
-            const int rr = r + half;
-            const bool rowok = rr <= cd;
-            const size_t q = (size_t)(gy + (rowok ? rr : 0)) * W + gx;
-            const int cl = rowok ? (int)aL[q] : 0;
-            const int width = rowok ? cl + (int)aR[q] + 1 : 0;
-            const int wmax = max(__shfl(width, 0), __shfl(width, 32));
-            for (int c0 = 0; c0 < wmax; c0 += 32) {
-                const int xo = c0 + l;
-                int code = -1; // -1: no vote (outside the row segment, or an outlier itself)
-                if (xo < width && gx - cl + xo >= 0 && gx - cl + xo < W) {
-                    const size_t s = q - cl + xo;
-                    if (outl[s] == 0) {
-                        const int b = (int)disp[s] + zd; // d_dr_irv.cu:200-201
-                        code = (b >= 0 && b < nb) ? b : -2; // -2: reliable, but its bin is out of range
+        for (int jb = 0; jb < nrows; jb += 128) { // 128 rows per outer step covers every usd <= 63 in one go
+            // horizontal arms of the region's rows, fetched once: lane <-> rows jb+lane and jb+64+lane
+            int cl0 = 0, w0 = 0, cl1 = 0, w1 = 0;
+            if (jb + lane < nrows) {
+                const size_t q = (size_t)(y_top + jb + lane) * W + gx;
+                cl0 = aL[q];
+                w0 = cl0 + (int)aR[q] + 1; // x-armL .. x+armR inclusive
+            }
+            if (jb + 64 + lane < nrows) {
+                const size_t q = (size_t)(y_top + jb + 64 + lane) * W + gx;
+                cl1 = aL[q];
+                w1 = cl1 + (int)aR[q] + 1;
+            }
+            const int jend = min(nrows - jb, 128);
+            for (int j0 = 0; j0 < jend; j0 += 2 * IV_U) {
+                // first 32 pixels of IV_U row pairs: all loads issued before any is consumed
+                u8 o[IV_U];
+                float dv[IV_U];
+                int wd[IV_U];
+#pragma unroll
+                for (int u = 0; u < IV_U; ++u) {
+                    const int ja = min(j0 + 2 * u, 127), jb2 = min(j0 + 2 * u + 1, 127); // rows of the two half-waves
+                    const int cl = half ? irv_row_value(cl0, cl1, jb2) : irv_row_value(cl0, cl1, ja);
+                    int w = half ? irv_row_value(w0, w1, jb2) : irv_row_value(w0, w1, ja);
+                    const int j = j0 + 2 * u + half; // this half-wave's row
+                    if (j >= jend) w = 0;
+                    wd[u] = w;
+                    const int sx = gx - cl + l;
+                    o[u] = 1;
+                    dv[u] = 0.f;
+                    if (l < w && sx >= 0 && sx < W) {
+                        const size_t s = (size_t)(y_top + jb + j) * W + sx;
+                        o[u] = outl[s];
+                        dv[u] = disp[s];
                     }
                 }
-                total += __popcll(__ballot(code != -1));
-                unsigned long long act = __ballot(code >= 0);
-                while (act) {
-                    const int leader = __ffsll((long long)act) - 1;
-                    const int b0 = __shfl(code, leader);
-                    const unsigned long long m = __ballot(code == b0);
-                    if (lane == leader) atomicAdd(&hist[b0], (uint32_t)__popcll(m));
-                    act &= ~m;
+#pragma unroll
+                for (int u = 0; u < IV_U; ++u) {
+                    int code = -1; // -1: no vote (outside the row segment, or an outlier itself)
+                    if (o[u] == 0) {
+                        const int b = (int)dv[u] + zd;      // d_dr_irv.cu:200-201
+                        code = (b >= 0 && b < nb) ? b : -2; // -2: reliable, but its bin is out of range
+                    }
+                    irv_tally(code, lane, hist, total);
+                }
+                // rows wider than 32 pixels: remaining chunks
+#pragma unroll
+                for (int u = 0; u < IV_U; ++u) {
+                    const int wmax = max(__builtin_amdgcn_readlane(wd[u], 0), __builtin_amdgcn_readlane(wd[u], 32));
+                    if (wmax <= 32) continue;
+                    const int j = j0 + 2 * u + half;
+                    const int ja = min(j0 + 2 * u, 127), jb2 = min(j0 + 2 * u + 1, 127);
+                    const int cl = half ? irv_row_value(cl0, cl1, jb2) : irv_row_value(cl0, cl1, ja);
+                    for (int c0 = 32; c0 < wmax; c0 += 32) {
+                        const int xo = c0 + l, sx = gx - cl + xo;
+                        int code = -1;
+                        if (xo < wd[u] && sx >= 0 && sx < W) {
+                            const size_t s = (size_t)(y_top + jb + j) * W + sx;
+                            if (outl[s] == 0) {
+                                const int b = (int)disp[s] + zd;
+                                code = (b >= 0 && b < nb) ? b : -2;
+                            }
+                        }
+                        irv_tally(code, lane, hist, total);
+                    }
                 }
             }
         }
@@ -133,8 +214,8 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(const float *__r
             uint32_t k = (c << 16) | (uint32_t)(0xFFFF - b);
             if (c != 0 && k > key) key = k;
         }
-        for (int o = 32; o >= 1; o >>= 1) {
-            uint32_t other = (uint32_t)__shfl_xor((int)key, o);
+        for (int o2 = 32; o2 >= 1; o2 >>= 1) {
+            uint32_t other = (uint32_t)__shfl_xor((int)key, o2);
             if (other > key) key = other;
         }
         if (lane == 0) {
@@ -175,7 +256,7 @@ void launch_irv(float *disp, u8 *outl, const u8 *up, const u8 *down, const u8 *l
     auto vote = [&]() {
         ProfScope p("irv_vote");
         STM_CHECK(hipMemsetAsync(counter, 0, sizeof(int), stream()));
-        hipLaunchKernelGGL(stm_k_irv_compact, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream(), outl, list, counter,
+        hipLaunchKernelGGL(stm_k_irv_compact, dim3((unsigned)((HW + 1023) / 1024)), dim3(256), 0, stream(), outl, list, counter,
                            (uint32_t)HW);
         STM_CHECK_LAUNCH();
         hipLaunchKernelGGL(stm_k_irv_vote, dim3(IV_BLOCKS), dim3(64 * IV_WAVES), smem, stream(), disp, outl, up, down, left,
