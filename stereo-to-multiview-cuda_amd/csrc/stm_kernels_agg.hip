@@ -112,96 +112,109 @@ static void allow_lds(const void *func, size_t bytes)
 }
 
 // ------------------------------------------------------------------ horizontal pass
-constexpr int AH_T = 256;    // threads per block
-constexpr int AH_QPB = 4;    // disparity quads per block (un-fused pass)
-constexpr int AH_MAXPPT = 16; // pixels per thread the register prefetch covers (W <= 4096)
+constexpr int AH_QPB = 4; // disparity quads per block (un-fused pass)
 
-// One block = one image row x `qpb` quads.  LDS: float4 tile[W] | u16 arms[W] (armL | armR << 8)
-// | (WTA only) best cost[W], best index[W].  While quad q is being summed out of LDS, quad q+1 is
-// already in flight from HBM into registers.
-template <bool QUAD, bool WTA>
-__global__ __launch_bounds__(AH_T) void stm_k_agg_h(Vol in, Vol out, const u8 *__restrict__ armL,
-                                                    const u8 *__restrict__ armR, float *__restrict__ disp,
-                                                    int D, int zd, int H, int W, int qpb)
+// One block (T threads) = one image row x `qpb` quads; a thread owns the pixels tid, tid+T, ... (at most PPT).
+// LDS: float4 tile[W] | u16 arms[W] (armL | armR << 8).  While quad q is being summed out of LDS, quad q+1
+// is already in flight from HBM into registers.  WTA: the running (best cost, best index) of the thread's
+// pixels stay in registers across all quads; the aggregated volume is never written.
+template <bool QUAD, bool WTA, int T, int PPT>
+__global__ __launch_bounds__(T) void stm_k_agg_h(Vol in, Vol out, const u8 *__restrict__ armL,
+                                                 const u8 *__restrict__ armR, float *__restrict__ disp,
+                                                 int D, int zd, int H, int W, int qpb)
 {
     extern __shared__ float4 smem4[];
     float4 *tile = smem4;
     uint16_t *arms = (uint16_t *)(tile + W);
-    float *best_c = (float *)(arms + ((W + 1) & ~1));
-    int *best_d = (int *)(best_c + W);
     const int y = blockIdx.x, tid = threadIdx.x;
     const size_t row = (size_t)y * W;
     const int nq = (D + 3) >> 2;
     const int q0 = blockIdx.y * qpb, q1 = min(q0 + qpb, nq);
-    const int ppt = (W + AH_T - 1) / AH_T;
 
-    for (int x = tid; x < W; x += AH_T) {
-        arms[x] = (uint16_t)armL[row + x] | ((uint16_t)armR[row + x] << 8);
-        if (WTA) { best_c[x] = 3.402823466e+38f; best_d[x] = 0; }
-    }
+    for (int x = tid; x < W; x += T) arms[x] = (uint16_t)armL[row + x] | ((uint16_t)armR[row + x] << 8);
 
-    float4 pre[AH_MAXPPT];
+    float4 pre[PPT];
+    float best_c[WTA ? PPT : 1];
+    int best_d[WTA ? PPT : 1];
 #pragma unroll
-    for (int i = 0; i < AH_MAXPPT; ++i) {
-        int x = tid + i * AH_T;
-        if (i < ppt && x < W) pre[i] = load_quad<QUAD>(in, q0, D, row + x);
+    for (int i = 0; i < PPT; ++i) {
+        const int x = tid + i * T;
+        if (x < W) pre[i] = load_quad<QUAD>(in, q0, D, row + x);
+        if (WTA) { best_c[i] = 3.402823466e+38f; best_d[i] = 0; }
     }
     for (int q = q0; q < q1; ++q) {
         __syncthreads(); // previous quad's readers are done with the tile (first time: arms visible)
 #pragma unroll
-        for (int i = 0; i < AH_MAXPPT; ++i) {
-            int x = tid + i * AH_T;
-            if (i < ppt && x < W) tile[x] = pre[i];
+        for (int i = 0; i < PPT; ++i) {
+            const int x = tid + i * T;
+            if (x < W) tile[x] = pre[i];
         }
         __syncthreads();
         if (q + 1 < q1) {
 #pragma unroll
-            for (int i = 0; i < AH_MAXPPT; ++i) {
-                int x = tid + i * AH_T;
-                if (i < ppt && x < W) pre[i] = load_quad<QUAD>(in, q + 1, D, row + x);
+            for (int i = 0; i < PPT; ++i) {
+                const int x = tid + i * T;
+                if (x < W) pre[i] = load_quad<QUAD>(in, q + 1, D, row + x);
             }
         }
         const int d0 = q * 4;
-        for (int x = tid; x < W; x += AH_T) {
-            uint32_t ar = arms[x];
-            int aL = (int)(ar & 0xff), n = aL + (int)(ar >> 8); // window [x - armL, x + armR)
-            float4 s = window_sum<1>(tile + (x - aL), n, make_float4(0.f, 0.f, 0.f, 0.f));
-            if (WTA) {
-                // first strictly-lowest cost wins, ascending d (d_dc_wta.cu:19-34)
-                float bc = best_c[x];
-                int bd = best_d[x];
-                if (bc > s.x) { bc = s.x; bd = d0; }
-                if (d0 + 1 < D && bc > s.y) { bc = s.y; bd = d0 + 1; }
-                if (d0 + 2 < D && bc > s.z) { bc = s.z; bd = d0 + 2; }
-                if (d0 + 3 < D && bc > s.w) { bc = s.w; bd = d0 + 3; }
-                best_c[x] = bc;
-                best_d[x] = bd;
-            } else {
-                store_quad<QUAD>(out, q, D, row + x, s);
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int x = tid + i * T;
+            if (x < W) {
+                const uint32_t ar = arms[x];
+                const int aL = (int)(ar & 0xff), n = aL + (int)(ar >> 8); // window [x - armL, x + armR)
+                const float4 s = window_sum<1>(tile + (x - aL), n, make_float4(0.f, 0.f, 0.f, 0.f));
+                if (WTA) {
+                    // first strictly-lowest cost wins, ascending d (d_dc_wta.cu:19-34)
+                    float bc = best_c[i];
+                    int bd = best_d[i];
+                    if (bc > s.x) { bc = s.x; bd = d0; }
+                    if (d0 + 1 < D && bc > s.y) { bc = s.y; bd = d0 + 1; }
+                    if (d0 + 2 < D && bc > s.z) { bc = s.z; bd = d0 + 2; }
+                    if (d0 + 3 < D && bc > s.w) { bc = s.w; bd = d0 + 3; }
+                    best_c[i] = bc;
+                    best_d[i] = bd;
+                } else {
+                    store_quad<QUAD>(out, q, D, row + x, s);
+                }
             }
         }
     }
-    if (WTA)
-        for (int x = tid; x < W; x += AH_T) disp[row + x] = (float)best_d[x] - (float)zd; // own pixels only
+    if (WTA) {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int x = tid + i * T;
+            if (x < W) disp[row + x] = (float)best_d[i] - (float)zd;
+        }
+    }
 }
 
-static size_t agg_h_smem(int W, bool wta)
+static size_t agg_h_smem(int W) { return (size_t)W * 16 + (size_t)((W + 1) & ~1) * 2; }
+
+template <bool QUAD, bool WTA, int T, int PPT>
+static void launch_agg_h_tt(Vol in, Vol out, const u8 *armL, const u8 *armR, float *disp, int D, int zd, int H, int W, int qpb)
 {
-    size_t s = (size_t)W * 16 + (size_t)((W + 1) & ~1) * 2;
-    if (wta) s += (size_t)W * 8;
-    return s;
+    int nq = (D + 3) / 4;
+    size_t smem = agg_h_smem(W);
+    allow_lds((const void *)stm_k_agg_h<QUAD, WTA, T, PPT>, smem);
+    hipLaunchKernelGGL((stm_k_agg_h<QUAD, WTA, T, PPT>), dim3(H, cdiv(nq, qpb)), dim3(T), smem, stream(), in, out, armL, armR,
+                       disp, D, zd, H, W, qpb);
+    STM_CHECK_LAUNCH();
 }
 
+// picks (threads, pixels per thread) so that T * PPT >= W with the smallest register footprint
 template <bool QUAD, bool WTA>
 static void launch_agg_h_t(Vol in, Vol out, const u8 *armL, const u8 *armR, float *disp, int D, int zd, int H, int W, int qpb)
 {
-    if (W > AH_T * AH_MAXPPT) fail("aggregation: num_cols > 4096 is not supported by the row-tile kernel", "W", __FILE__, __LINE__);
-    int nq = (D + 3) / 4;
-    size_t smem = agg_h_smem(W, WTA);
-    allow_lds((const void *)stm_k_agg_h<QUAD, WTA>, smem);
-    hipLaunchKernelGGL((stm_k_agg_h<QUAD, WTA>), dim3(H, cdiv(nq, qpb)), dim3(AH_T), smem, stream(), in, out, armL, armR, disp,
-                       D, zd, H, W, qpb);
-    STM_CHECK_LAUNCH();
+    const int hv = (agg_variant() / 100) % 10;
+    if (W > 8192) fail("aggregation: num_cols > 8192 is not supported by the row-tile kernel", "W", __FILE__, __LINE__);
+    if (hv == 1 && W <= 2048) launch_agg_h_tt<QUAD, WTA, 256, 8>(in, out, armL, armR, disp, D, zd, H, W, qpb);
+    else if (hv == 2 && W <= 2048) launch_agg_h_tt<QUAD, WTA, 1024, 2>(in, out, armL, armR, disp, D, zd, H, W, qpb);
+    else if (W <= 1024) launch_agg_h_tt<QUAD, WTA, 256, 4>(in, out, armL, armR, disp, D, zd, H, W, qpb);
+    else if (W <= 2048) launch_agg_h_tt<QUAD, WTA, 512, 4>(in, out, armL, armR, disp, D, zd, H, W, qpb);
+    else if (W <= 4096) launch_agg_h_tt<QUAD, WTA, 1024, 4>(in, out, armL, armR, disp, D, zd, H, W, qpb);
+    else launch_agg_h_tt<QUAD, WTA, 1024, 8>(in, out, armL, armR, disp, D, zd, H, W, qpb);
 }
 
 void launch_agg_h(Vol in, Vol out, const u8 *armL, const u8 *armR, int D, int H, int W)
@@ -222,102 +235,121 @@ void launch_agg_h_wta(Vol in, const u8 *armL, const u8 *armR, float *disp, int D
 }
 
 // ------------------------------------------------------------------ vertical pass
-constexpr int AV_TX = 32; // columns per block
-constexpr int AV_TY = 8;  // thread rows per block (256 threads) == output rows per step
-
-// One block = AV_TX columns x a band of rows x one quad.  Rows stream top to bottom through an LDS ring
-// of R = roundup(2 usd, AV_TY) + AV_TY rows (row r lives in slot r % R; R is a multiple of AV_TY and every
-// band starts at a multiple of AV_TY, so slots advance without any division).  A window wraps around the
-// ring at most once and is summed as two linear segments.  The rows of the next step are fetched from HBM
-// into registers while the current step is summed.
-template <bool QUAD>
-__global__ __launch_bounds__(AV_TX *AV_TY) void stm_k_agg_v(Vol in, Vol out, const u8 *__restrict__ armU,
-                                                            const u8 *__restrict__ armD, int D, int H, int W, int usd,
-                                                            int R, int band)
+// One block = TX columns x a band of rows x one quad; TX x TY threads, every thread owns OPT rows of each
+// step (CH = TY * OPT output rows per step).  Rows stream top to bottom through an LDS ring of
+// R = roundup(2 usd, CH) + CH rows (row r lives in slot r % R; R is a multiple of CH and every band starts
+// at a multiple of CH, so slots advance without any division).  A window wraps around the ring at most
+// once and is summed as two linear segments.  The CH rows of the next step are fetched from HBM into
+// registers while the current step is summed; a step costs two barriers, amortised over CH rows.
+template <bool QUAD, int TX, int TY, int OPT>
+__global__ __launch_bounds__(TX *TY) void stm_k_agg_v(Vol in, Vol out, const u8 *__restrict__ armU,
+                                                      const u8 *__restrict__ armD, int D, int H, int W, int usd, int R,
+                                                      int band)
 {
+    constexpr int CH = TY * OPT;
     extern __shared__ float4 ring[];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int x = blockIdx.x * AV_TX + tx;
+    const int x = blockIdx.x * TX + tx;
     const int yb0 = blockIdx.y * band, yb1 = min(yb0 + band, H);
     const int q = blockIdx.z;
     const bool xin = x < W;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // initial fill: rows [first, yb0 + usd) of the first step's needs minus its own AV_TY-row prefetch below
+    // initial fill: rows [first, yb0 + usd - 1); every step then adds the CH rows it prefetched
     const int first = max(yb0 - usd, 0);
-    int slot_first = first % R;
-    int loaded = min(yb0 + usd - 1, H); // rows [first, loaded) go in now; the per-step prefetch adds AV_TY rows
+    const int slot_first = first % R;
+    int loaded = min(yb0 + usd - 1, H);
     if (loaded < first) loaded = first;
-    for (int r = first + ty; r < loaded; r += AV_TY) {
+    for (int r = first + ty; r < loaded; r += TY) {
         int s = slot_first + (r - first);
         if (s >= R) s -= R;
-        ring[s * AV_TX + tx] = xin ? load_quad<QUAD>(in, q, D, (size_t)r * W + x) : zero4;
+        ring[s * TX + tx] = xin ? load_quad<QUAD>(in, q, D, (size_t)r * W + x) : zero4;
     }
     int slot_loaded = slot_first + (loaded - first);
     if (slot_loaded >= R) slot_loaded -= R;
     int slot_y0 = yb0 % R;
 
-    // prefetch for the first step: rows [loaded, loaded + AV_TY)
-    float4 pre = zero4;
-    {
-        int r = loaded + ty;
-        if (xin && r < H) pre = load_quad<QUAD>(in, q, D, (size_t)r * W + x);
+    float4 pre[OPT];
+#pragma unroll
+    for (int i = 0; i < OPT; ++i) {
+        const int r = loaded + ty + i * TY;
+        pre[i] = (xin && r < H) ? load_quad<QUAD>(in, q, D, (size_t)r * W + x) : zero4;
     }
-    for (int y0 = yb0; y0 < yb1; y0 += AV_TY) {
+    for (int y0 = yb0; y0 < yb1; y0 += CH) {
         __syncthreads(); // everyone finished the previous step before its oldest rows are overwritten
-        {
-            int r = loaded + ty;
-            int s = slot_loaded + ty;
+#pragma unroll
+        for (int i = 0; i < OPT; ++i) {
+            const int r = loaded + ty + i * TY;
+            int s = slot_loaded + ty + i * TY;
             if (s >= R) s -= R;
-            if (r < H) ring[s * AV_TX + tx] = pre;
+            if (r < H) ring[s * TX + tx] = pre[i];
         }
-        loaded += AV_TY;
-        slot_loaded += AV_TY;
+        loaded += CH;
+        slot_loaded += CH;
         if (slot_loaded >= R) slot_loaded -= R;
         __syncthreads();
-        {
-            int r = loaded + ty; // next step's row, in flight during this step's sums
-            if (xin && r < H && y0 + AV_TY < yb1) pre = load_quad<QUAD>(in, q, D, (size_t)r * W + x);
+        if (y0 + CH < yb1) { // next step's rows, in flight during this step's sums
+#pragma unroll
+            for (int i = 0; i < OPT; ++i) {
+                const int r = loaded + ty + i * TY;
+                if (xin && r < H) pre[i] = load_quad<QUAD>(in, q, D, (size_t)r * W + x);
+            }
         }
-        const int y = y0 + ty;
-        if (xin && y < yb1) {
-            const size_t p = (size_t)y * W + x;
-            const int aU = (int)armU[p], n = aU + (int)armD[p]; // window [y - armU, y + armD)
-            int sa = slot_y0 + ty - aU;
-            if (sa < 0) sa += R;
-            const int n1 = min(n, R - sa);
-            float4 s = window_sum<AV_TX>(ring + sa * AV_TX + tx, n1, zero4);
-            s = window_sum<AV_TX>(ring + tx, n - n1, s);
-            store_quad<QUAD>(out, q, D, p, s);
+#pragma unroll
+        for (int i = 0; i < OPT; ++i) {
+            const int y = y0 + ty + i * TY;
+            if (xin && y < yb1) {
+                const size_t p = (size_t)y * W + x;
+                const int aU = (int)armU[p], n = aU + (int)armD[p]; // window [y - armU, y + armD)
+                int sa = slot_y0 + ty + i * TY - aU;
+                if (sa < 0) sa += R;
+                const int n1 = min(n, R - sa);
+                float4 s = window_sum<TX>(ring + sa * TX + tx, n1, zero4);
+                s = window_sum<TX>(ring + tx, n - n1, s);
+                store_quad<QUAD>(out, q, D, p, s);
+            }
         }
-        slot_y0 += AV_TY;
+        slot_y0 += CH;
         if (slot_y0 >= R) slot_y0 -= R;
     }
 }
 
-static int av_band(int H)
+template <bool QUAD, int TX, int TY, int OPT>
+static void launch_agg_v_t(Vol in, Vol out, const u8 *armU, const u8 *armD, int D, int H, int W, int usd, int nbands)
 {
-    int b = (cdiv(H, 2) + AV_TY - 1) / AV_TY * AV_TY; // two bands: +usd/H halo re-reads, twice the blocks
-    return b < AV_TY ? AV_TY : b;
+    constexpr int CH = TY * OPT;
+    int nq = (D + 3) / 4;
+    int R = (2 * usd + CH - 1) / CH * CH + CH;
+    size_t smem = (size_t)R * TX * 16;
+    int band = (cdiv(H, nbands) + CH - 1) / CH * CH; // a few bands: +usd rows of halo each, more blocks in flight
+    if (band < CH) band = CH;
+    allow_lds((const void *)stm_k_agg_v<QUAD, TX, TY, OPT>, smem);
+    hipLaunchKernelGGL((stm_k_agg_v<QUAD, TX, TY, OPT>), dim3(cdiv(W, TX), cdiv(H, band), nq), dim3(TX, TY), smem, stream(), in,
+                       out, armU, armD, D, H, W, usd, R, band);
+    STM_CHECK_LAUNCH();
 }
 
 void launch_agg_v(Vol in, Vol out, const u8 *armU, const u8 *armD, int D, int H, int W, int usd)
 {
-    int nq = (D + 3) / 4;
-    int R = (2 * usd + AV_TY - 1) / AV_TY * AV_TY + AV_TY;
-    size_t smem = (size_t)R * AV_TX * 16;
-    int band = av_band(H);
     ProfScope p("agg_v");
+    const int v = agg_variant() % 100;
+    const int nbands = (v / 10) ? (v / 10) : 3;
     if (in.quad) {
-        allow_lds((const void *)stm_k_agg_v<true>, smem);
-        hipLaunchKernelGGL(stm_k_agg_v<true>, dim3(cdiv(W, AV_TX), cdiv(H, band), nq), dim3(AV_TX, AV_TY), smem, stream(),
-                           in, out, armU, armD, D, H, W, usd, R, band);
+        switch (v % 10) {
+        default: launch_agg_v_t<true, 16, 32, 1>(in, out, armU, armD, D, H, W, usd, nbands); break;
+        case 1: launch_agg_v_t<true, 32, 8, 2>(in, out, armU, armD, D, H, W, usd, nbands); break;
+        case 2: launch_agg_v_t<true, 32, 8, 4>(in, out, armU, armD, D, H, W, usd, nbands); break;
+        case 3: launch_agg_v_t<true, 16, 16, 2>(in, out, armU, armD, D, H, W, usd, nbands); break;
+        case 4: launch_agg_v_t<true, 16, 16, 4>(in, out, armU, armD, D, H, W, usd, nbands); break;
+        case 5: launch_agg_v_t<true, 64, 4, 4>(in, out, armU, armD, D, H, W, usd, nbands); break;
+        case 6: launch_agg_v_t<true, 16, 16, 1>(in, out, armU, armD, D, H, W, usd, nbands); break;
+        case 7: launch_agg_v_t<true, 16, 8, 1>(in, out, armU, armD, D, H, W, usd, nbands); break;
+        case 8: launch_agg_v_t<true, 16, 32, 1>(in, out, armU, armD, D, H, W, usd, nbands); break;
+        case 9: launch_agg_v_t<true, 8, 32, 1>(in, out, armU, armD, D, H, W, usd, nbands); break;
+        }
     } else {
-        allow_lds((const void *)stm_k_agg_v<false>, smem);
-        hipLaunchKernelGGL(stm_k_agg_v<false>, dim3(cdiv(W, AV_TX), cdiv(H, band), nq), dim3(AV_TX, AV_TY), smem, stream(),
-                           in, out, armU, armD, D, H, W, usd, R, band);
+        launch_agg_v_t<false, 32, 16, 1>(in, out, armU, armD, D, H, W, usd, nbands); // 128-B row segments per plane
     }
-    STM_CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------ WTA (un-fused, per-stage API)
