@@ -134,7 +134,7 @@ def main():
         alg = {"agg_h": 2 * V + 2 * HW, "agg_v": 2 * V + 2 * HW, "agg_hw": V + 2 * HW + 4 * HW,
                "cost_init": 2 * V + 4 * 4 * HW}
         kern = {}
-        for name in ["agg_h", "agg_v", "agg_hw", "cost_init", "cross_arms", "irv_vote", "bilateral", "gaussian_max",
+        for name in ["agg_h", "agg_v", "agg_hw", "cost_init", "cross_arms", "irv", "bilateral", "gaussian_max",
                      "view_synth", "mux"]:
             n, ms = dev.prof_read(name)
             if n:

@@ -294,27 +294,25 @@ void stm_d_dr_irv(float *d_disp, unsigned char *d_outliers, unsigned char **d_cr
                   int num_rows, int num_cols, int num_disp, int zero_disp, int usd, int iterations)
 {
     size_t HW = (size_t)num_rows * num_cols;
-    Workspace::begin(12 * HW + 4096);
+    Workspace::begin(20 * HW + 8192);
     Arms a = arms_from_table(d_cross);
-    int *md = Workspace::get<int>(HW), *rel = Workspace::get<int>(HW);
-    uint32_t *lst = Workspace::get<uint32_t>(HW);
-    int *cnt = Workspace::get<int>(1);
-    launch_irv(d_disp, d_outliers, a.up, a.down, a.left, a.right, md, rel, lst, cnt, thresh_s, thresh_h, num_rows, num_cols, num_disp,
-               zero_disp, usd, iterations, true);
+    float *dv[1] = {d_disp};
+    u8 *ov[1] = {d_outliers};
+    const u8 *u[1] = {a.up}, *d[1] = {a.down}, *l[1] = {a.left}, *r[1] = {a.right};
+    launch_irv(1, dv, ov, u, d, l, r, thresh_s, thresh_h, num_rows, num_cols, num_disp, zero_disp, usd, iterations, true);
 }
 void stm_dr_irv(float *disp, unsigned char *outliers, unsigned char **cross, int thresh_s, float thresh_h, int num_rows,
                 int num_cols, int num_disp, int zero_disp, int usd, int iterations)
 {
     size_t HW = (size_t)num_rows * num_cols;
-    Workspace::begin(24 * HW + 8192);
+    Workspace::begin(28 * HW + 16384);
     float *d = up(disp, HW);
     u8 *o = up(outliers, HW);
     Arms a{up(cross[0], HW), up(cross[1], HW), up(cross[2], HW), up(cross[3], HW)};
-    int *md = Workspace::get<int>(HW), *rel = Workspace::get<int>(HW);
-    uint32_t *lst = Workspace::get<uint32_t>(HW);
-    int *cnt = Workspace::get<int>(1);
-    launch_irv(d, o, a.up, a.down, a.left, a.right, md, rel, lst, cnt, thresh_s, thresh_h, num_rows, num_cols, num_disp, zero_disp, usd,
-               iterations, false);
+    float *dv[1] = {d};
+    u8 *ov[1] = {o};
+    const u8 *uu[1] = {a.up}, *dd[1] = {a.down}, *ll[1] = {a.left}, *rr[1] = {a.right};
+    launch_irv(1, dv, ov, uu, dd, ll, rr, thresh_s, thresh_h, num_rows, num_cols, num_disp, zero_disp, usd, iterations, false);
     down(disp, d, HW); down(outliers, o, HW);
     sync();
 }
@@ -518,11 +516,12 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
     STM_CHECK(hipMemsetAsync(outl_l, 0, HW, stream())); // d_io.cu:138-141
     STM_CHECK(hipMemsetAsync(outl_r, 0, HW, stream()));
     launch_dcc(outl_l, outl_r, d_disp_l, d_disp_r, hit_l, hit_r, H, W);
-    int *md = Workspace::get<int>(HW), *rel = Workspace::get<int>(HW);
-    uint32_t *lst = Workspace::get<uint32_t>(HW);
-    int *cnt = Workspace::get<int>(1);
-    launch_irv(d_disp_l, outl_l, al.up, al.down, al.left, al.right, md, rel, lst, cnt, thresh_s, thresh_h, H, W, D, zero_disp, usd, 5, true); // :147
-    launch_irv(d_disp_r, outl_r, ar.up, ar.down, ar.left, ar.right, md, rel, lst, cnt, thresh_s, thresh_h, H, W, D, zero_disp, usd, 5, true); // :148
+    {   // d_io.cu:147-148, both views per launch
+        float *dv[2] = {d_disp_l, d_disp_r};
+        u8 *ov[2] = {outl_l, outl_r};
+        const u8 *u[2] = {al.up, ar.up}, *d[2] = {al.down, ar.down}, *l[2] = {al.left, ar.left}, *r[2] = {al.right, ar.right};
+        launch_irv(2, dv, ov, u, d, l, r, thresh_s, thresh_h, H, W, D, zero_disp, usd, 5, true);
+    }
     core_bilateral(d_disp_l, 7, 5.0f, 10.0f, H, W, D); // :150
     core_bilateral(d_disp_r, 7, 5.0f, 10.0f, H, W, D); // :151
     if (stages < 3) return;

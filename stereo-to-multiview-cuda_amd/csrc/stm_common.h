@@ -100,8 +100,10 @@ void launch_agg_h_wta(Vol in, const u8 *armL, const u8 *armR, float *disp, int D
 void launch_wta(Vol cost, float *disp, int D, int zd, int H, int W);
 // refinement (stm_kernels_refine.hip)
 void launch_dcc(u8 *out_l, u8 *out_r, const float *disp_l, const float *disp_r, u8 *hit_l, u8 *hit_r, int H, int W);
-void launch_irv(float *disp, u8 *outl, const u8 *up, const u8 *down, const u8 *left, const u8 *right,
-                int *max_disp, int *reliable, uint32_t *list, int *counter, int thresh_s, float thresh_h,
+// nviews = 1 or 2 (both views of a frame share every launch); scratch comes from the current Workspace scope
+// (16 bytes per pixel per view)
+void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const *up, const u8 *const *down,
+                const u8 *const *left, const u8 *const *right, int thresh_s, float thresh_h,
                 int H, int W, int D, int zd, int usd, int iterations, bool device_flavour);
 void launch_bilateral(const float *in, float *out, const float *spatial, const float *color,
                       int radius, int H, int W, int D);

@@ -63,10 +63,23 @@ void launch_dcc(u8 *out_l, u8 *out_r, const float *disp_l, const float *disp_r, 
 // counted in a per-wave LDS histogram, and the winner is a wave-wide max over (count, -bin).
 // Every outlier's result is independent of the list order, so the atomic compaction is deterministic
 // where it matters.  Histogram: max(D,65) bins (the reference's int[65] overflows for D > 65, A-Q17 ii).
+// Both views of a frame go through every IRV launch together (blockIdx.y = view).
+struct IrvArgs {
+    float *disp[2];
+    u8 *outl[2];
+    const u8 *aU[2], *aD[2], *aL[2], *aR[2];
+    int *max_disp[2], *reliable[2];
+    uint32_t *list_a[2], *list_b[2]; // ping-pong outlier lists
+    int *counts[2];                  // counts[v][k] = length of the list that iteration k votes on
+    u8 *dirty[2];                    // dirty[v][it][tile]: a pixel of the 64x64 tile was accepted in iteration it
+};
+
 // four pixels per thread (one dword of the u8 outlier map); one global atomic per WAVE that holds any outlier
-__global__ __launch_bounds__(256) void stm_k_irv_compact(const u8 *__restrict__ outl, uint32_t *__restrict__ list,
-                                                         int *__restrict__ count, uint32_t HW)
+__global__ __launch_bounds__(256) void stm_k_irv_compact(IrvArgs a, uint32_t HW)
 {
+    const int v = blockIdx.y;
+    const u8 *__restrict__ outl = a.outl[v];
+    uint32_t *__restrict__ list = a.list_a[v];
     const uint32_t p = (blockIdx.x * 256u + threadIdx.x) * 4u;
     const int lane = threadIdx.x & 63;
     uint32_t w = 0;
@@ -85,7 +98,7 @@ __global__ __launch_bounds__(256) void stm_k_irv_compact(const u8 *__restrict__ 
     }
     const int wave_total = __shfl(incl, 63);
     int base = 0;
-    if (lane == 0) base = atomicAdd(count, wave_total);
+    if (lane == 0) base = atomicAdd(&a.counts[v][0], wave_total);
     base = __shfl(base, 0);
     int k = base + incl - c;
 #pragma unroll
@@ -94,7 +107,7 @@ __global__ __launch_bounds__(256) void stm_k_irv_compact(const u8 *__restrict__ 
 }
 
 constexpr int IV_WAVES = 4;     // waves per block
-constexpr int IV_BLOCKS = 2048; // persistent grid
+constexpr int IV_BLOCKS = 1024; // persistent grid per view
 constexpr int IV_U = 4;         // row pairs whose loads are in flight together
 
 // value held by lane (j & 63) of v0 (j < 64) or v1 (j >= 64), for a wave-uniform j
@@ -106,71 +119,90 @@ __device__ __forceinline__ int irv_row_value(int v0, int v1, int j)
 // one LDS atomic per voting lane: equal bins serialise inside the LDS atomic unit (<= 64 cycles), which beats a
 // ballot-merge loop whenever a step sees more than a couple of distinct disparities -- and outliers sit exactly
 // where the disparity map is noisy
-__device__ __forceinline__ void irv_tally(int code, int lane, uint32_t *hist, int &total)
+__device__ __forceinline__ void irv_tally(int code, uint32_t *hist, int &total)
 {
     total += __popcll(__ballot(code != -1));
     if (code >= 0) atomicAdd(&hist[code], 1u);
 }
 
-__global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(const float *__restrict__ disp, const u8 *__restrict__ outl,
-                                                                const u8 *__restrict__ aU, const u8 *__restrict__ aD,
-                                                                const u8 *__restrict__ aL, const u8 *__restrict__ aR,
-                                                                const uint32_t *__restrict__ list, const int *__restrict__ count,
-                                                                int *__restrict__ max_disp, int *__restrict__ reliable,
-                                                                int H, int W, int nb, int zd, int usd)
+// iteration `it` (0-based) votes on list (it even ? list_a : list_b) of length counts[v][it].
+// One wave per outlier, one region row per wave step (lanes = pixels of the row segment, coalesced), IV_U rows
+// in flight together.  The kernel is instruction-issue bound (8 waves per SIMD hide all latency), so everything
+// that is uniform over the wave is kept in SGPRs: row arms are fetched once into lanes and broadcast with
+// v_readlane, row offsets are 32-bit scalar arithmetic.
+// Pruning: an outlier whose cross region saw no accepted pixel in the previous iteration would repeat its
+// previous vote exactly (the vote is a pure function of the region), so it is skipped; `dirty` holds one byte
+// per 64x64 tile and iteration, set by the apply kernel.
+constexpr int IV_TILE = 64;
+__global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int it, int H, int W, int nb, int zd, int usd,
+                                                                int tiles_x, int tiles_y)
 {
     extern __shared__ uint32_t hist_all[]; // [IV_WAVES][nb]
+    const int v = blockIdx.y;
+    const float *__restrict__ disp = a.disp[v];
+    const u8 *__restrict__ outl = a.outl[v];
+    const u8 *__restrict__ aL = a.aL[v], *__restrict__ aR = a.aR[v];
+    const uint32_t *__restrict__ list = (it & 1) ? a.list_b[v] : a.list_a[v];
+    const u8 *__restrict__ dirty = it > 0 ? a.dirty[v] + (size_t)(it - 1) * tiles_x * tiles_y : nullptr;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int half = lane >> 5, l = lane & 31;
     uint32_t *hist = hist_all + wave * nb;
-    const int n = *count;
+    const int n = a.counts[v][it];
     for (int i = blockIdx.x * IV_WAVES + wave; i < n; i += gridDim.x * IV_WAVES) {
-        const uint32_t p = list[i];
-        const int gy = (int)(p / (uint32_t)W), gx = (int)(p - (uint32_t)gy * (uint32_t)W);
-        for (int b = lane; b < nb; b += 64) hist[b] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        int cu = aU[p], cd = aD[p];
+        const int p = __builtin_amdgcn_readfirstlane((int)list[i]);
+        const int gy = p / W, gx = p - gy * W;
+        int cu = a.aU[v][p], cd = a.aD[v][p];
         if (cu > usd) cu = usd;   // d_dr_irv.cu:179-180
         cu = min(cu, gy);         // arms built by ca_cross never leave the image; these two clamps only keep a
         cd = min(cd, H - 1 - gy); // caller who passes inconsistent arms from reading outside the planes
-        const int nrows = cu + cd + 1; // rows gy-cu .. gy+cd inclusive (SURVEY A-Q17 iii), at most 2*255+1
+        cu = __builtin_amdgcn_readfirstlane(cu);
+        cd = __builtin_amdgcn_readfirstlane(cd);
+        if (dirty) { // bounding box of the region = [gx-usd, gx+usd] x [gy-cu, gy+cd]: at most 3x3 tiles of 64
+            const int tx0 = max(gx - usd, 0) / IV_TILE, tx1 = min(gx + usd, W - 1) / IV_TILE;
+            const int ty0 = (gy - cu) / IV_TILE, ty1 = (gy + cd) / IV_TILE;
+            const int nx = tx1 - tx0 + 1, nt = nx * (ty1 - ty0 + 1);
+            int d = nt > 64; // more tiles than lanes (usd > 95): do not prune
+            if (lane < nt) d = dirty[(ty0 + lane / nx) * tiles_x + tx0 + lane % nx];
+            if (__ballot(d != 0) == 0) continue; // same region contents as last time -> same vote (already stored)
+        }
+        for (int b = lane; b < nb; b += 64) hist[b] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nrows = cu + cd + 1; // rows gy-cu .. gy+cd inclusive (SURVEY A-Q17 iii)
         const int y_top = gy - cu;
         int total = 0;
         for (int jb = 0; jb < nrows; jb += 128) { // 128 rows per outer step covers every usd <= 63 in one go
             // horizontal arms of the region's rows, fetched once: lane <-> rows jb+lane and jb+64+lane
             int cl0 = 0, w0 = 0, cl1 = 0, w1 = 0;
             if (jb + lane < nrows) {
-                const size_t q = (size_t)(y_top + jb + lane) * W + gx;
+                const int q = (y_top + jb + lane) * W + gx;
                 cl0 = aL[q];
                 w0 = cl0 + (int)aR[q] + 1; // x-armL .. x+armR inclusive
             }
             if (jb + 64 + lane < nrows) {
-                const size_t q = (size_t)(y_top + jb + 64 + lane) * W + gx;
+                const int q = (y_top + jb + 64 + lane) * W + gx;
                 cl1 = aL[q];
                 w1 = cl1 + (int)aR[q] + 1;
             }
             const int jend = min(nrows - jb, 128);
-            for (int j0 = 0; j0 < jend; j0 += 2 * IV_U) {
-                // first 32 pixels of IV_U row pairs: all loads issued before any is consumed
+            for (int j0 = 0; j0 < jend; j0 += IV_U) {
                 u8 o[IV_U];
                 float dv[IV_U];
-                int wd[IV_U];
+                int wd[IV_U], base[IV_U];
 #pragma unroll
-                for (int u = 0; u < IV_U; ++u) {
-                    const int ja = min(j0 + 2 * u, 127), jb2 = min(j0 + 2 * u + 1, 127); // rows of the two half-waves
-                    const int cl = half ? irv_row_value(cl0, cl1, jb2) : irv_row_value(cl0, cl1, ja);
-                    int w = half ? irv_row_value(w0, w1, jb2) : irv_row_value(w0, w1, ja);
-                    const int j = j0 + 2 * u + half; // this half-wave's row
-                    if (j >= jend) w = 0;
+                for (int u = 0; u < IV_U; ++u) { // first 64 pixels of IV_U rows: all loads issued before any is consumed
+                    const int j = min(j0 + u, 127);
+                    int cl = irv_row_value(cl0, cl1, j), w = irv_row_value(w0, w1, j);
+                    if (j0 + u >= jend) w = 0;
+                    int xs = gx - cl; // scalar; clamp the segment into the row (no-op for consistent arms)
+                    if (xs < 0) { w += xs; xs = 0; }
+                    w = min(w, W - xs);
                     wd[u] = w;
-                    const int sx = gx - cl + l;
+                    base[u] = (y_top + jb + j) * W + xs;
                     o[u] = 1;
                     dv[u] = 0.f;
-                    if (l < w && sx >= 0 && sx < W) {
-                        const size_t s = (size_t)(y_top + jb + j) * W + sx;
-                        o[u] = outl[s];
-                        dv[u] = disp[s];
+                    if (lane < w) {
+                        o[u] = outl[base[u] + lane];
+                        dv[u] = disp[base[u] + lane];
                     }
                 }
 #pragma unroll
@@ -180,27 +212,17 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(const float *__r
                         const int b = (int)dv[u] + zd;      // d_dr_irv.cu:200-201
                         code = (b >= 0 && b < nb) ? b : -2; // -2: reliable, but its bin is out of range
                     }
-                    irv_tally(code, lane, hist, total);
+                    irv_tally(code, hist, total);
                 }
-                // rows wider than 32 pixels: remaining chunks
 #pragma unroll
-                for (int u = 0; u < IV_U; ++u) {
-                    const int wmax = max(__builtin_amdgcn_readlane(wd[u], 0), __builtin_amdgcn_readlane(wd[u], 32));
-                    if (wmax <= 32) continue;
-                    const int j = j0 + 2 * u + half;
-                    const int ja = min(j0 + 2 * u, 127), jb2 = min(j0 + 2 * u + 1, 127);
-                    const int cl = half ? irv_row_value(cl0, cl1, jb2) : irv_row_value(cl0, cl1, ja);
-                    for (int c0 = 32; c0 < wmax; c0 += 32) {
-                        const int xo = c0 + l, sx = gx - cl + xo;
+                for (int u = 0; u < IV_U; ++u) { // segments wider than 64 pixels (arm sum >= 64): rare
+                    for (int c0 = 64; c0 < wd[u]; c0 += 64) {
                         int code = -1;
-                        if (xo < wd[u] && sx >= 0 && sx < W) {
-                            const size_t s = (size_t)(y_top + jb + j) * W + sx;
-                            if (outl[s] == 0) {
-                                const int b = (int)disp[s] + zd;
-                                code = (b >= 0 && b < nb) ? b : -2;
-                            }
+                        if (c0 + lane < wd[u] && outl[base[u] + c0 + lane] == 0) {
+                            const int b = (int)disp[base[u] + c0 + lane] + zd;
+                            code = (b >= 0 && b < nb) ? b : -2;
                         }
-                        irv_tally(code, lane, hist, total);
+                        irv_tally(code, hist, total);
                     }
                 }
             }
@@ -221,58 +243,79 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(const float *__r
         if (lane == 0) {
             int max_d = (int)disp[p]; // default: own disparity (d_dr_irv.cu:182)
             if (key != 0) max_d = (0xFFFF - (int)(key & 0xFFFF)) - zd;
-            max_disp[p] = max_d;
-            reliable[p] = total;
+            a.max_disp[v][p] = max_d;
+            a.reliable[v][p] = total;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-__global__ __launch_bounds__(256) void stm_k_irv_apply(float *__restrict__ disp, u8 *__restrict__ outl,
-                                                       const int *__restrict__ max_disp, int *__restrict__ reliable,
-                                                       int thresh_s, float thresh_h, int zd, size_t HW)
+// dr_irv_kernel_3 (d_dr_irv.cu:17-43) over the outlier list only (it touches nothing else), fused with the
+// construction of the next iteration's list: pixels that stay outliers are appended to the other list.
+__global__ __launch_bounds__(256) void stm_k_irv_apply(IrvArgs a, int it, int thresh_s, float thresh_h, int zd, int W,
+                                                       int tiles_x, int tiles_y)
 {
-    size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
-    if (outl[p] != 0) {
-        int tr = reliable[p], md = max_disp[p];
+    const int v = blockIdx.y;
+    const uint32_t *__restrict__ list = (it & 1) ? a.list_b[v] : a.list_a[v];
+    uint32_t *__restrict__ next = (it & 1) ? a.list_a[v] : a.list_b[v];
+    const int n = a.counts[v][it];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t p = list[i];
+        const int tr = a.reliable[v][p], md = a.max_disp[v][p];
         // ratio uses the winning BIN INDEX, not its count (d_dr_irv.cu:36, SURVEY A-Q17 iv)
         if (tr > thresh_s && (float)(md + zd) / (float)tr > thresh_h) {
-            outl[p] = 0;
-            reliable[p] = tr + 1;
-            disp[p] = (float)md;
+            a.outl[v][p] = 0;
+            a.reliable[v][p] = tr + 1;
+            a.disp[v][p] = (float)md;
+            const int gy = (int)(p / (uint32_t)W), gx = (int)(p - (uint32_t)gy * (uint32_t)W);
+            a.dirty[v][(size_t)it * tiles_x * tiles_y + (gy / IV_TILE) * tiles_x + gx / IV_TILE] = 1; // same value from every writer
+        } else {
+            next[atomicAdd(&a.counts[v][it + 1], 1)] = p; // wave-aggregated by the compiler
         }
     }
 }
 
-void launch_irv(float *disp, u8 *outl, const u8 *up, const u8 *down, const u8 *left, const u8 *right, int *max_disp,
-                int *reliable, uint32_t *list, int *counter, int thresh_s, float thresh_h, int H, int W, int D, int zd,
+void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const *up, const u8 *const *down,
+                const u8 *const *left, const u8 *const *right, int thresh_s, float thresh_h, int H, int W, int D, int zd,
                 int usd, int iterations, bool device_flavour)
 {
-    size_t HW = (size_t)H * W;
-    int nb = D > 65 ? D : 65;
-    size_t smem = (size_t)nb * IV_WAVES * 4;
-    auto vote = [&]() {
-        ProfScope p("irv_vote");
-        STM_CHECK(hipMemsetAsync(counter, 0, sizeof(int), stream()));
-        hipLaunchKernelGGL(stm_k_irv_compact, dim3((unsigned)((HW + 1023) / 1024)), dim3(256), 0, stream(), outl, list, counter,
-                           (uint32_t)HW);
+    const size_t HW = (size_t)H * W;
+    const int nb = D > 65 ? D : 65;
+    if (nviews < 1 || nviews > 2) fail("launch_irv: 1 or 2 views", "nviews", __FILE__, __LINE__);
+    // host flavour (d_dr_irv.cu:344-353): one vote, then `iterations` applies of which only the first can change anything
+    const int rounds = device_flavour ? iterations : (iterations > 0 ? 1 : 0);
+    IrvArgs a;
+    const int tiles_x = cdiv(W, IV_TILE), tiles_y = cdiv(H, IV_TILE);
+    const size_t dirty_sz = (size_t)(rounds + 1) * tiles_x * tiles_y;
+    int *counts = Workspace::get<int>(2 * (size_t)(rounds + 2) + (2 * dirty_sz + 3) / 4); // counters, then dirty bytes: one memset
+    for (int v = 0; v < 2; ++v) {
+        const int s = v < nviews ? v : 0;
+        a.disp[v] = disp[s]; a.outl[v] = outl[s];
+        a.aU[v] = up[s]; a.aD[v] = down[s]; a.aL[v] = left[s]; a.aR[v] = right[s];
+        a.counts[v] = counts + (size_t)v * (rounds + 2);
+        a.dirty[v] = (u8 *)(counts + 2 * (size_t)(rounds + 2)) + (size_t)v * dirty_sz;
+    }
+    for (int v = 0; v < nviews; ++v) {
+        a.max_disp[v] = Workspace::get<int>(HW);
+        a.reliable[v] = Workspace::get<int>(HW);
+        a.list_a[v] = Workspace::get<uint32_t>(HW);
+        a.list_b[v] = Workspace::get<uint32_t>(HW);
+    }
+    if (nviews == 1) { a.max_disp[1] = a.max_disp[0]; a.reliable[1] = a.reliable[0]; a.list_a[1] = a.list_a[0]; a.list_b[1] = a.list_b[0]; }
+    if (rounds == 0) return; // nothing observable happens (a host-flavour vote without an apply only fills scratch)
+    ProfScope p("irv");
+    STM_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * 2 * (size_t)(rounds + 2) + 2 * dirty_sz, stream()));
+    hipLaunchKernelGGL(stm_k_irv_compact, dim3((unsigned)((HW + 1023) / 1024), nviews), dim3(256), 0, stream(), a, (uint32_t)HW);
+    STM_CHECK_LAUNCH();
+    const size_t smem = (size_t)nb * IV_WAVES * 4;
+    for (int it = 0; it < rounds; ++it) {
+        hipLaunchKernelGGL(stm_k_irv_vote, dim3(IV_BLOCKS, nviews), dim3(64 * IV_WAVES), smem, stream(), a, it, H, W, nb, zd, usd,
+                           tiles_x, tiles_y);
         STM_CHECK_LAUNCH();
-        hipLaunchKernelGGL(stm_k_irv_vote, dim3(IV_BLOCKS), dim3(64 * IV_WAVES), smem, stream(), disp, outl, up, down, left,
-                           right, list, counter, max_disp, reliable, H, W, nb, zd, usd);
+        hipLaunchKernelGGL(stm_k_irv_apply, dim3(256, nviews), dim3(256), 0, stream(), a, it, thresh_s, thresh_h, zd, W, tiles_x,
+                           tiles_y);
         STM_CHECK_LAUNCH();
-    };
-    auto apply = [&]() {
-        hipLaunchKernelGGL(stm_k_irv_apply, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream(), disp, outl, max_disp,
-                           reliable, thresh_s, thresh_h, zd, HW);
-        STM_CHECK_LAUNCH();
-    };
-    if (device_flavour) { // d_dr_irv.cu:259-265
-        for (int i = 0; i < iterations; ++i) { vote(); apply(); }
-    } else { // d_dr_irv.cu:344-353
-        vote();
-        for (int i = 0; i < iterations; ++i) apply();
     }
 }
 
