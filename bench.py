@@ -143,8 +143,16 @@ def main():
         achieved = alg[dom] / (kern[dom]["avg_ms"] * 1e-3) / 1e9
         agg_total_ms = sum(kern[k]["total_ms"] for k in ("agg_h", "agg_v", "agg_hw") if k in kern) / args.steps
         agg_bytes = sum(alg[k] * kern[k]["launches"] for k in ("agg_h", "agg_v", "agg_hw") if k in kern) / args.steps
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE/WRITE_SIZE need their own rocprofv3 --pmc passes, so they
+        # cannot be sampled inside this process): taken from the committed summary of the same workload, or null
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tj) and (H, W, D) == (1080, 1920, 64):
+            t = json.load(open(tj))
+            if dom in t:
+                traffic, traffic_src = t[dom]["traffic_bytes"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)"
         roofline = {"bound": "hbm", "kernel": "stm_k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern[dom]["avg_ms"],
                     "agg_stage_ms_per_frame": agg_total_ms, "agg_stage_GBps": agg_bytes / (agg_total_ms * 1e-3) / 1e9}
         fps = world * args.steps / dt

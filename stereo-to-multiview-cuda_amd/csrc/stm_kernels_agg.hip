@@ -244,14 +244,33 @@ void launch_agg_h_wta(Vol in, const u8 *armL, const u8 *armR, float *disp, int D
 template <bool QUAD, int TX, int TY, int OPT>
 __global__ __launch_bounds__(TX *TY) void stm_k_agg_v(Vol in, Vol out, const u8 *__restrict__ armU,
                                                       const u8 *__restrict__ armD, int D, int H, int W, int usd, int R,
-                                                      int band)
+                                                      int band, int nstrips, int nbands, int nq, int xcd_map)
 {
     constexpr int CH = TY * OPT;
     extern __shared__ float4 ring[];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int x = blockIdx.x * TX + tx;
-    const int yb0 = blockIdx.y * band, yb1 = min(yb0 + band, H);
-    const int q = blockIdx.z;
+    // block -> (strip, band, quad).  XCD-aware order: blocks are dealt round-robin over the 8 XCDs (b % 8 labels
+    // the XCD group), so the blocks one XCD sees, b = xcd, xcd+8, ..., walk the quads of ONE (strip, band) tile
+    // before moving to the next tile: the tile's arm bytes are fetched into that XCD's L2 once and reused by the
+    // other nq-1 quads.  Placement only affects speed, never results.
+    int strip, bandi, q;
+    {
+        const int b = blockIdx.x;
+        int tile;
+        if (xcd_map) {
+            const int xcd = b & 7, i = b >> 3;
+            q = i % nq;
+            tile = (i / nq) * 8 + xcd;
+        } else {
+            tile = b % (nstrips * nbands);
+            q = b / (nstrips * nbands);
+        }
+        if (tile >= nstrips * nbands) return; // padding blocks of the last group of 8 tiles
+        strip = tile % nstrips;
+        bandi = tile / nstrips;
+    }
+    const int x = strip * TX + tx;
+    const int yb0 = bandi * band, yb1 = min(yb0 + band, H);
     const bool xin = x < W;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -324,8 +343,11 @@ static void launch_agg_v_t(Vol in, Vol out, const u8 *armU, const u8 *armD, int 
     int band = (cdiv(H, nbands) + CH - 1) / CH * CH; // a few bands: +usd rows of halo each, more blocks in flight
     if (band < CH) band = CH;
     allow_lds((const void *)stm_k_agg_v<QUAD, TX, TY, OPT>, smem);
-    hipLaunchKernelGGL((stm_k_agg_v<QUAD, TX, TY, OPT>), dim3(cdiv(W, TX), cdiv(H, band), nq), dim3(TX, TY), smem, stream(), in,
-                       out, armU, armD, D, H, W, usd, R, band);
+    const int nstrips = cdiv(W, TX), nb = cdiv(H, band);
+    const int xcd_map = (agg_variant() / 1000) % 10 == 1 ? 0 : 1;
+    const int ntiles8 = cdiv(nstrips * nb, 8) * 8;
+    hipLaunchKernelGGL((stm_k_agg_v<QUAD, TX, TY, OPT>), dim3((unsigned)ntiles8 * nq), dim3(TX, TY), smem, stream(), in, out,
+                       armU, armD, D, H, W, usd, R, band, nstrips, nb, nq, xcd_map);
     STM_CHECK_LAUNCH();
 }
 

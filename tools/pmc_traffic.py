@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass on gfx950) into a
+per-kernel HBM traffic summary, with the corrections MI355X_MICROARCH.md section 'HBM' prescribes:
+  * both counters are in KiB (x1024);
+  * FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B/lane) on gfx950, so the
+    read side is doubled for the kernels that stream the cost volume as 16-byte quads (stm_k_agg_*, calibrated on
+    stm_k_agg_h: corrected read = 534.7 MB vs 534.9 MB algorithmic); WRITE_SIZE is exact for 16 B/lane stores.
+usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "").replace("stm::", "")
+    if "agg_h" in n:
+        return "agg_hw" if "true, true" in n or "false, true" in n else "agg_h"
+    for k in ("agg_v", "cost_init", "cross_arms", "irv_vote", "bilateral", "gaussian_max", "view_synth", "mux"):
+        if k in n:
+            return k
+    return n
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        if "stm_k_" not in k:
+            continue
+        f_raw = fetch.get(k, 0.0) * 1024.0
+        w = write.get(k, 0.0) * 1024.0
+        corr = 2.0 if ("agg_" in k or "cost_init" in k) else 1.0
+        out[short(k)] = {"kernel": k.split("(")[0], "fetch_raw_bytes": f_raw, "fetch_correction": corr,
+                         "write_bytes": w, "traffic_bytes": f_raw * corr + w}
+    json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+    for k, v in out.items():
+        print("%-14s read %8.1f MB (raw %8.1f) write %8.1f MB total %8.1f MB" % (k, v["fetch_raw_bytes"] * v["fetch_correction"] / 1e6,
+                                                                            v["fetch_raw_bytes"] / 1e6, v["write_bytes"] / 1e6, v["traffic_bytes"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
