@@ -139,7 +139,7 @@ void core_dbm(u8 *d_out, const u8 *d_l, const u8 *d_r, const float *disp_l, cons
 {
     size_t HW = (size_t)H * W;
     float *blend = Workspace::get<float>(HW);
-    launch_gaussian_max(mask_r, blend, gauss2d_table(g_radius, g_sigma), g_radius, H, W, true); // G(1 - maskR)
+    launch_gaussian_max(mask_r, blend, gauss2d_table(g_radius, g_sigma), g_radius, g_sigma, H, W, true); // G(1 - maskR)
     launch_view_synth(d_out, d_l, d_r, disp_l, disp_r, mask_l, mask_r, blend, shift, H, W, elem_sz);
 }
 
@@ -339,7 +339,7 @@ void stm_d_filter_gaussian_1(float *d_img, int radius, float sigma_spatial, int 
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(HW * 4 + 1024);
     float *tmp = Workspace::get<float>(HW);
-    launch_gaussian_max(d_img, tmp, gauss2d_table(radius, sigma_spatial), radius, num_rows, num_cols, false);
+    launch_gaussian_max(d_img, tmp, gauss2d_table(radius, sigma_spatial), radius, sigma_spatial, num_rows, num_cols, false);
     STM_CHECK(hipMemcpyAsync(d_img, tmp, HW * 4, hipMemcpyDeviceToDevice, stream())); // d_filter_gaussian.cu:171
 }
 void stm_filter_gaussian_1(float *img, int radius, float sigma_spatial, int num_rows, int num_cols)
@@ -347,7 +347,7 @@ void stm_filter_gaussian_1(float *img, int radius, float sigma_spatial, int num_
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(8 * HW + 4096);
     float *d = up(img, HW), *tmp = Workspace::get<float>(HW);
-    launch_gaussian_max(d, tmp, gauss2d_table(radius, sigma_spatial), radius, num_rows, num_cols, false);
+    launch_gaussian_max(d, tmp, gauss2d_table(radius, sigma_spatial), radius, sigma_spatial, num_rows, num_cols, false);
     down(img, tmp, HW);
     sync();
 }
@@ -506,8 +506,11 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
     core_ci(img_l, img_r, cl, cr, pk_l, pk_r, ad_coeff, census_coeff, D, zero_disp, H, W, elem_sz);
 
     Arms al = carve_arms(HW), ar = carve_arms(HW);
-    launch_cross_arms(pk_l, al.up, al.down, al.left, al.right, ucd, lcd, usd, lsd, H, W);
-    launch_cross_arms(pk_r, ar.up, ar.down, ar.left, ar.right, ucd, lcd, usd, lsd, H, W);
+    {
+        const uint32_t *pk[2] = {pk_l, pk_r};
+        u8 *u[2] = {al.up, ar.up}, *d[2] = {al.down, ar.down}, *l[2] = {al.left, ar.left}, *r[2] = {al.right, ar.right};
+        launch_cross_arms2(2, pk, u, d, l, r, ucd, lcd, usd, lsd, H, W);
+    }
     core_agg_wta(cl, sc, al, d_disp_l, D, zero_disp, H, W, usd);
     core_agg_wta(cr, sc, ar, d_disp_r, D, zero_disp, H, W, usd);
     if (stages < 2) return;
@@ -534,7 +537,7 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
     STM_CHECK(hipMemcpyAsync(occl_r, tmp8, HW, hipMemcpyDeviceToDevice, stream()));
     float *mask_l = Workspace::get<float>(HW), *mask_r = Workspace::get<float>(HW), *blend = Workspace::get<float>(HW);
     launch_occl_to_mask(mask_l, mask_r, occl_l, occl_r, H, W); // :175-176
-    launch_gaussian_max(mask_r, blend, gauss2d_table(10, 15.0f), 10, H, W, true); // d_dibr_bwarp.cu:60-63, once per frame
+    launch_gaussian_max(mask_r, blend, gauss2d_table(10, 15.0f), 10, 15.0f, H, W, true); // d_dibr_bwarp.cu:60-63, once per frame
 
     u8 *views_mem = Workspace::get<u8>((size_t)N * IMG);
     // views[0] = right image, views[N-1] = left image (d_io.cu:182-183)

@@ -94,6 +94,8 @@ void launch_cost_init(const uint32_t *pk_l, const uint32_t *pk_r, const uint32_t
 // aggregation (stm_kernels_agg.hip)
 void launch_cross_arms(const uint32_t *packed, u8 *up, u8 *down, u8 *left, u8 *right,
                        float ucd, float lcd, int usd, int lsd, int H, int W);
+void launch_cross_arms2(int nviews, const uint32_t *const *packed, u8 *const *up, u8 *const *down, u8 *const *left,
+                        u8 *const *right, float ucd, float lcd, int usd, int lsd, int H, int W);
 void launch_agg_h(Vol in, Vol out, const u8 *armL, const u8 *armR, int D, int H, int W);
 void launch_agg_v(Vol in, Vol out, const u8 *armU, const u8 *armD, int D, int H, int W, int usd);
 void launch_agg_h_wta(Vol in, const u8 *armL, const u8 *armR, float *disp, int D, int zd, int H, int W);
@@ -107,7 +109,8 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
                 int H, int W, int D, int zd, int usd, int iterations, bool device_flavour);
 void launch_bilateral(const float *in, float *out, const float *spatial, const float *color,
                       int radius, int H, int W, int D);
-void launch_gaussian_max(const float *in, float *out, const float *spatial, int radius, int H, int W, bool invert_input);
+void launch_gaussian_max(const float *in, float *out, const float *spatial, int radius, float sigma, int H, int W,
+                         bool invert_input);
 // DIBR + mux (stm_kernels_dibr.hip)
 void launch_demux_sbs(u8 *l, u8 *r, const u8 *sbs, int H, int Wsbs, int W, int elem_sz);
 void launch_occl(u8 *occl_l, u8 *occl_r, const float *disp_l, const float *disp_r, int H, int W);

@@ -29,57 +29,84 @@ __device__ __forceinline__ int mad_bgrx(uint32_t a, uint32_t b)
 {
     int d0 = abs((int)(a & 0xff) - (int)(b & 0xff));
     int d1 = abs((int)((a >> 8) & 0xff) - (int)((b >> 8) & 0xff));
-    int d2 = abs((int)((a >> 16) & 0xff) - (int)((b >> 16) & 0xff));
+    int d2 = abs((int)(a >> 16) - (int)(b >> 16));
     return max(max(d0, d1), d2);
 }
 
-// arm along (dx,dy): value recorded BEFORE the colour test (SURVEY A-Q9, d_ca_cross.cu:41-69)
-__device__ __forceinline__ int one_arm(const uint32_t *__restrict__ img, int W, int H, int tx, int ty, int dx, int dy,
-                                       float ucd, float lcd, int usd, int lsd, uint32_t anchor)
+// One arm: walk k = 1..kmax pixels from the anchor (kmax = min(usd, distance to the border): the reference's
+// border test, d_ca_cross.cu:44-45, hoisted out of the loop).  The arm value is recorded BEFORE the colour
+// test (SURVEY A-Q9, :47-64): near tier (k <= lsd) stops when anchor-vs-current or previous-vs-current exceeds
+// lcd, far tier when anchor-vs-current exceeds ucd.  `(float)int > float` is evaluated as int > floor(float),
+// which is the same predicate for every integer left-hand side.
+__device__ __forceinline__ int one_arm(const uint32_t *__restrict__ p, int stride, int kmax, int lsd, int t_far, int t_near,
+                                       uint32_t anchor)
 {
     uint32_t prev = anchor;
     int arm = 0;
-    for (int k = 1; k <= usd; ++k) {
-        int cx = tx + dx * k, cy = ty + dy * k;
-        if (cx < 0 || cy < 0 || cx > W - 1 || cy > H - 1) break;
+    for (int k = 1; k <= kmax; ++k) {
+        p += stride;
+        const uint32_t c = *p;
         arm = k;
-        uint32_t c = img[(size_t)cy * W + cx];
-        int ac = mad_bgrx(c, anchor), cp = mad_bgrx(c, prev);
+        const int ac = mad_bgrx(c, anchor);
         if (k > lsd) {
-            if ((float)ac > ucd) break;
+            if (ac > t_far) break;
         } else {
-            if ((float)ac > lcd || (float)cp > lcd) break;
+            if (ac > t_near || mad_bgrx(c, prev) > t_near) break;
+            prev = c;
         }
-        prev = c;
     }
     return arm;
 }
 
-__global__ __launch_bounds__(256) void stm_k_cross_arms(const uint32_t *__restrict__ img, u8 *__restrict__ up,
-                                                        u8 *__restrict__ down, u8 *__restrict__ left,
-                                                        u8 *__restrict__ right, float ucd, float lcd, int usd, int lsd,
-                                                        int H, int W)
+struct ArmsArgs {
+    const uint32_t *img[2];
+    u8 *up[2], *down[2], *left[2], *right[2];
+};
+
+__global__ __launch_bounds__(256) void stm_k_cross_arms(ArmsArgs a, int t_far, int t_near, int usd, int lsd, int H, int W)
 {
-    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int v = blockIdx.z;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
-    size_t p = (size_t)y * W + x;
-    uint32_t a = img[p];
-    up[p] = (u8)one_arm(img, W, H, x, y, 0, -1, ucd, lcd, usd, lsd, a);
-    down[p] = (u8)one_arm(img, W, H, x, y, 0, 1, ucd, lcd, usd, lsd, a);
-    left[p] = (u8)one_arm(img, W, H, x, y, -1, 0, ucd, lcd, usd, lsd, a);
-    right[p] = (u8)one_arm(img, W, H, x, y, 1, 0, ucd, lcd, usd, lsd, a);
+    const int p = y * W + x;
+    const uint32_t *__restrict__ img = a.img[v] + p;
+    const uint32_t anchor = *img;
+    a.up[v][p] = (u8)one_arm(img, -W, min(usd, y), lsd, t_far, t_near, anchor);
+    a.down[v][p] = (u8)one_arm(img, W, min(usd, H - 1 - y), lsd, t_far, t_near, anchor);
+    a.left[v][p] = (u8)one_arm(img, -1, min(usd, x), lsd, t_far, t_near, anchor);
+    a.right[v][p] = (u8)one_arm(img, 1, min(usd, W - 1 - x), lsd, t_far, t_near, anchor);
+}
+
+static int int_threshold(float t)
+{
+    if (t != t) return 1 << 30;    // NaN: '>' is never true
+    if (t >= 256.f) return 1 << 30; // above any 8-bit difference
+    if (t < 0.f) return -1;         // every difference (>= 0) exceeds it
+    return (int)floorf(t);
+}
+
+// nviews = 1 or 2: both views of a frame share the launch
+void launch_cross_arms2(int nviews, const uint32_t *const *packed, u8 *const *up, u8 *const *down, u8 *const *left,
+                        u8 *const *right, float ucd, float lcd, int usd, int lsd, int H, int W)
+{
+    ArmsArgs a;
+    for (int v = 0; v < 2; ++v) {
+        const int s = v < nviews ? v : 0;
+        a.img[v] = packed[s]; a.up[v] = up[s]; a.down[v] = down[s]; a.left[v] = left[s]; a.right[v] = right[s];
+    }
+    if (usd > 255) usd = 255; // arms are stored as u8 (reference T2)
+    ProfScope p("cross_arms");
+    hipLaunchKernelGGL(stm_k_cross_arms, dim3(cdiv(W, 256), H, nviews), dim3(256), 0, stream(), a, int_threshold(ucd),
+                       int_threshold(lcd), usd, lsd, H, W);
+    STM_CHECK_LAUNCH();
 }
 
 void launch_cross_arms(const uint32_t *packed, u8 *up, u8 *down, u8 *left, u8 *right, float ucd, float lcd, int usd,
                        int lsd, int H, int W)
 {
-    ProfScope p("cross_arms");
-    hipLaunchKernelGGL(stm_k_cross_arms, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), packed, up, down, left, right,
-                       ucd, lcd, usd, lsd, H, W);
-    STM_CHECK_LAUNCH();
+    launch_cross_arms2(1, &packed, &up, &down, &left, &right, ucd, lcd, usd, lsd, H, W);
 }
 
-// ------------------------------------------------------------------ helpers
 #define STM_ACC(s, v) { s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w; }
 
 // s += p[0] + p[S] + ... + p[(n-1)S], added strictly left to right (the reference's order,

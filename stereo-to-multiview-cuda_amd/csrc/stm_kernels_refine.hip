@@ -10,6 +10,10 @@
 // follow the reference loops exactly (row-major taps, sequential float adds, no contraction).
 #include "stm_common.h"
 
+#include <map>
+#include <utility>
+#include <vector>
+
 namespace stm {
 
 // ------------------------------------------------------------------ L/R check
@@ -319,6 +323,126 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
     }
 }
 
+// ------------------------------------------------------------------ stencils, fast path
+// Compile-time radius, four adjacent output pixels per thread: a tile row is read once as aligned float4s and
+// reused by the four pixels (LDS reads per tap drop 4x), the spatial weights are wave-uniform and come in through
+// scalar loads (no LDS slot, no VGPR), taps are accumulated per pixel in the reference's row-major order.
+constexpr int SF_TX = 16, SF_TY = 16; // threads; a block covers 64 x 16 output pixels
+
+template <int R>
+__global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_gaussian_max_r(const float *__restrict__ in, float *__restrict__ out,
+                                                                    const float *__restrict__ spatial, float norm, int H, int W,
+                                                                    int invert)
+{
+    constexpr int KW = 2 * R + 1, NF = (KW + 3 + 3) / 4 * 4; // floats a thread needs per tile row, rounded to float4s
+    constexpr int TW = (SF_TX * 4 + 2 * R + 3) / 4 * 4 + 4, TH = SF_TY + 2 * R;
+    __shared__ float4 tile4[TH * TW / 4];
+    float *tile = (float *)tile4;
+    const int tid = threadIdx.y * SF_TX + threadIdx.x;
+    const int x0 = blockIdx.x * SF_TX * 4, y0 = blockIdx.y * SF_TY;
+    for (int i = tid; i < TH * TW; i += SF_TX * SF_TY) {
+        const int ty = i / TW, tx = i - ty * TW;
+        const int gx = min(max(x0 + tx - R, 0), W - 1), gy = min(max(y0 + ty - R, 0), H - 1); // clamp border (d_filter_gaussian.cu:39)
+        const float v = in[(size_t)gy * W + gx];
+        tile[i] = invert ? 1.0f - v : v;
+    }
+    __syncthreads();
+    const int gx = x0 + threadIdx.x * 4, gy = y0 + threadIdx.y;
+    if (gx >= W || gy >= H) return;
+    float res[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int y = 0; y < KW; ++y) {
+        float row[NF];
+        const float4 *src = (const float4 *)(tile + (threadIdx.y + y) * TW + threadIdx.x * 4);
+#pragma unroll
+        for (int j = 0; j < NF / 4; ++j) {
+            const float4 t = src[j];
+            row[4 * j] = t.x; row[4 * j + 1] = t.y; row[4 * j + 2] = t.z; row[4 * j + 3] = t.w;
+        }
+        const float *krow = spatial + y * KW; // uniform address -> scalar loads
+#pragma unroll
+        for (int x = 0; x < KW; ++x) {
+            const float w = krow[x];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float t = row[x + i] * w;
+                res[i] = res[i] + t;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (gx + i < W) {
+            const float va = tile[(threadIdx.y + R) * TW + threadIdx.x * 4 + i + R];
+            const float q = res[i] / norm;
+            out[(size_t)gy * W + gx + i] = (va < q) ? q : va; // d_filter_gaussian.cu:84-87
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_bilateral_r(const float *__restrict__ in, float *__restrict__ out,
+                                                                 const float *__restrict__ spatial,
+                                                                 const float *__restrict__ color, int H, int W, int ncolor)
+{
+    constexpr int KW = 2 * R + 1, NF = (KW + 3 + 3) / 4 * 4;
+    constexpr int TW = (SF_TX * 4 + 2 * R + 3) / 4 * 4 + 4, TH = SF_TY + 2 * R;
+    __shared__ float4 tile4[TH * TW / 4];
+    extern __shared__ float ck[]; // colour LUT, ncolor entries
+    float *tile = (float *)tile4;
+    const int tid = threadIdx.y * SF_TX + threadIdx.x;
+    const int x0 = blockIdx.x * SF_TX * 4, y0 = blockIdx.y * SF_TY;
+    for (int i = tid; i < TH * TW; i += SF_TX * SF_TY) {
+        const int ty = i / TW, tx = i - ty * TW;
+        const int gx = min(max(x0 + tx - R, 0), W - 1), gy = min(max(y0 + ty - R, 0), H - 1);
+        tile[i] = in[(size_t)gy * W + gx];
+    }
+    for (int i = tid; i < ncolor; i += SF_TX * SF_TY) ck[i] = color[i];
+    __syncthreads();
+    const int gx = x0 + threadIdx.x * 4, gy = y0 + threadIdx.y;
+    if (gx >= W || gy >= H) return;
+    float va[4], res[4] = {0.f, 0.f, 0.f, 0.f}, norm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) va[i] = tile[(threadIdx.y + R) * TW + threadIdx.x * 4 + i + R];
+    for (int y = 0; y < KW; ++y) {
+        float row[NF];
+        const float4 *src = (const float4 *)(tile + (threadIdx.y + y) * TW + threadIdx.x * 4);
+#pragma unroll
+        for (int j = 0; j < NF / 4; ++j) {
+            const float4 t = src[j];
+            row[4 * j] = t.x; row[4 * j + 1] = t.y; row[4 * j + 2] = t.z; row[4 * j + 3] = t.w;
+        }
+        const float *krow = spatial + y * KW;
+#pragma unroll
+        for (int x = 0; x < KW; ++x) {
+            const float gs = krow[x];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float vs = row[x + i];
+                int ci = (int)fabsf(va[i] - vs); // d_filter_bilateral.cu:295
+                ci = min(ci, ncolor - 1);
+                const float w = gs * ck[ci];
+                norm[i] = norm[i] + w;
+                const float t = vs * w;
+                res[i] = res[i] + t;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (gx + i < W) out[(size_t)gy * W + gx + i] = res[i] / norm[i];
+}
+
+// sum of the weights in tap order, float32, exactly as every pixel's `norm = norm + weight` chain computes it
+static float stencil_norm(int radius, float sigma)
+{
+    const int kw = 2 * radius + 1;
+    std::vector<float> k((size_t)kw * kw);
+    gaussian_kernel_2d(k.data(), radius, sigma);
+    volatile float n = 0.0f;
+    for (int i = 0; i < kw * kw; ++i) n = n + k[i];
+    return n;
+}
+
 // ------------------------------------------------------------------ stencils
 constexpr int ST_TX = 64, ST_TY = 4;
 
@@ -364,6 +488,13 @@ __global__ __launch_bounds__(ST_TX *ST_TY) void stm_k_bilateral(const float *__r
 void launch_bilateral(const float *in, float *out, const float *spatial, const float *color, int radius, int H, int W,
                       int D)
 {
+    if (radius == 7) {
+        ProfScope p("bilateral");
+        hipLaunchKernelGGL(stm_k_bilateral_r<7>, dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY)), dim3(SF_TX, SF_TY), (size_t)D * 4, stream(),
+                           in, out, spatial, color, H, W, D);
+        STM_CHECK_LAUNCH();
+        return;
+    }
     int tw = ST_TX + 2 * radius, th = ST_TY + 2 * radius, kw = 2 * radius + 1;
     size_t smem = (size_t)(tw * th + kw * kw + D) * 4;
     ProfScope p("bilateral");
@@ -408,8 +539,24 @@ __global__ __launch_bounds__(ST_TX *ST_TY) void stm_k_gaussian_max(const float *
     out[(size_t)gy * W + gx] = (va < q) ? q : va; // d_filter_gaussian.cu:84-87
 }
 
-void launch_gaussian_max(const float *in, float *out, const float *spatial, int radius, int H, int W, bool invert_input)
+void launch_gaussian_max(const float *in, float *out, const float *spatial, int radius, float sigma, int H, int W,
+                         bool invert_input)
 {
+    if (radius == 10 || radius == 7) {
+        static std::map<std::pair<int, float>, float> norms;
+        auto key = std::make_pair(radius, sigma);
+        auto it = norms.find(key);
+        if (it == norms.end()) it = norms.emplace(key, stencil_norm(radius, sigma)).first;
+        ProfScope p("gaussian_max");
+        if (radius == 10)
+            hipLaunchKernelGGL(stm_k_gaussian_max_r<10>, dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY)), dim3(SF_TX, SF_TY), 0, stream(), in,
+                               out, spatial, it->second, H, W, invert_input ? 1 : 0);
+        else
+            hipLaunchKernelGGL(stm_k_gaussian_max_r<7>, dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY)), dim3(SF_TX, SF_TY), 0, stream(), in,
+                               out, spatial, it->second, H, W, invert_input ? 1 : 0);
+        STM_CHECK_LAUNCH();
+        return;
+    }
     int tw = ST_TX + 2 * radius, th = ST_TY + 2 * radius, kw = 2 * radius + 1;
     size_t smem = (size_t)(tw * th + kw * kw) * 4;
     ProfScope p("gaussian_max");
