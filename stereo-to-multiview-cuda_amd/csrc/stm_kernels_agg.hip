@@ -235,7 +235,10 @@ template <bool QUAD, bool WTA>
 static void launch_agg_h_t(Vol in, Vol out, const u8 *armL, const u8 *armR, float *disp, int D, int zd, int H, int W, int qpb)
 {
     const int hv = (agg_variant() / 100) % 10;
-    if (W > 8192) fail("aggregation: num_cols > 8192 is not supported by the row-tile kernel", "W", __FILE__, __LINE__);
+    if (W > 8192) {
+        fail("aggregation: num_cols > 8192 is not supported by the row-tile kernel", "W", __FILE__, __LINE__);
+        return; // only reached in error mode 1 (record and return)
+    }
     if (hv == 1 && W <= 2048) launch_agg_h_tt<QUAD, WTA, 256, 8>(in, out, armL, armR, disp, D, zd, H, W, qpb);
     else if (hv == 2 && W <= 2048) launch_agg_h_tt<QUAD, WTA, 1024, 2>(in, out, armL, armR, disp, D, zd, H, W, qpb);
     else if (W <= 1024) launch_agg_h_tt<QUAD, WTA, 256, 4>(in, out, armL, armR, disp, D, zd, H, W, qpb);

@@ -276,3 +276,138 @@ def test_full_size_properties_1080p(gpu_ready):
     dev.d_adcensus_stm(torch.from_numpy(sbs2).cuda(), dl, dr, out, p, stages=1)
     torch.cuda.synchronize()
     assert float(dl.max()) <= 0 and float(dr.max()) <= 0
+
+
+# ----------------------------------------------------------------------------- edge cases
+EDGE = [
+    # H, W, D, zd, usd, lsd
+    (1, 1, 1, 0, 3, 1),        # a single pixel
+    (3, 5, 2, 1, 9, 4),        # arms longer than the image
+    (2, 70, 5, 4, 34, 17),     # two rows, window wider than a wave
+    (9, 17, 3, 7, 5, 2),       # zero_disp outside [0, D): every offset negative
+    (70, 33, 6, 2, 40, 10),    # usd > 32: wide IRV rows; H just above one V-pass step
+    (150, 40, 4, 1, 70, 20),   # usd = 70: IRV regions taller than 128 rows, ring of 2*70 rows
+]
+
+
+@pytest.mark.parametrize("H,W,D,zd,usd,lsd", EDGE)
+def test_edge_cases_stage_chain(api, orc, H, W, D, zd, usd, lsd):
+    L, R = rand_pair(max(H, 8), max(W, 8), 101 + H + W)
+    L, R = np.ascontiguousarray(L[:H, :W]), np.ascontiguousarray(R[:H, :W])
+    cl, cr = api.ci_adcensus(L, R, 10.0, 30.0, D, zd)
+    ocl, ocr = orc.ci_adcensus(L, R, 10.0, 30.0, D, zd)
+    assert np.array_equal(cl, ocl) and np.array_equal(cr, ocr)
+    xl, al = api.ca_cross(L, ocl, 6.0, 20.0, usd, lsd)
+    oxl, oal = orc.ca_cross(L, ocl, 6.0, 20.0, usd, lsd)
+    assert np.array_equal(xl, oxl) and np.array_equal(al, oal)
+    _, oar = orc.ca_cross(R, ocr, 6.0, 20.0, usd, lsd)
+    dl, dr = orc.dc_wta(oal, zd), orc.dc_wta(oar, zd)
+    assert np.array_equal(api.dc_wta(oal, zd), dl)
+    ol, orr = api.dr_dcc(dl, dr)
+    wol, worr = orc.dr_dcc(dl, dr)
+    assert np.array_equal(ol, wol) and np.array_equal(orr, worr)
+    il, iol = api.dr_irv(dl, wol, oxl, 1, 0.0, D, zd, usd, 2)
+    wl, wo = orc.dr_irv(dl, wol, oxl, 1, 0.0, D, zd, usd, 2, device_flavour=False)
+    assert np.array_equal(il, wl) and np.array_equal(iol, wo)
+    assert np.array_equal(api.filter_bilateral_1(dl, 7, 5.0, 10.0, max(D, 2)), orc.filter_bilateral_1(dl, 7, 5.0, 10.0, max(D, 2)))
+
+
+@pytest.mark.parametrize("H,W,D", [(6, 2100, 5), (4, 4200, 4)])
+def test_wide_rows_use_the_bigger_row_tiles(api, orc, H, W, D):
+    """W > 2048 and W > 4096 switch the H pass to 1024-thread blocks with 4 / 8 pixels per thread."""
+    L, _ = rand_pair(8, W, 7)
+    L = np.ascontiguousarray(L[:H])
+    cost = (np.random.RandomState(W).random_sample((D, H, W)) * 2).astype(np.float32)
+    x, a = api.ca_cross(L, cost, 6.0, 20.0, 34, 17)
+    ox, oa = orc.ca_cross(L, cost, 6.0, 20.0, 34, 17)
+    assert np.array_equal(x, ox) and np.array_equal(a, oa)
+
+
+def test_baseline_config4_shape_d128(gpu_ready, orc):
+    """BASELINE config 4 (D=128, 8-view DIBR + mux) on a reduced frame: IRV histogram > 65 bins (SURVEY A-L7)."""
+    import torch
+    from stm_amd import device_api as dev, synth
+    H, W, D, zd = 96, 256, 128, 64
+    sbs, _ = synth.sbs_frame(H, W, D, zd)
+    p = dev.FrameParams(num_disp=D, zero_disp=zd, usd=17, lsd=8)
+    dl = torch.zeros(H, W, dtype=torch.float32, device="cuda")
+    dr = torch.zeros_like(dl)
+    out = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+    dev.d_adcensus_stm(torch.from_numpy(sbs).cuda(), dl, dr, out, p, stages=3)
+    torch.cuda.synchronize()
+    want = orc.adcensus_stm(sbs, H, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd, p.usd,
+                            p.lsd, p.thresh_s, p.thresh_h)
+    assert np.array_equal(dl.cpu().numpy(), want["disp_l"]) and np.array_equal(dr.cpu().numpy(), want["disp_r"])
+    assert np.array_equal(out.cpu().numpy(), want["interlaced"])
+
+
+def test_real_image_statistics_irv_heavy(gpu_ready, orc, golden):
+    """A frame with MANY outliers (random right view): exercises IRV lists, pruning and multi-iteration apply."""
+    import torch
+    from stm_amd import device_api as dev
+    rng = np.random.RandomState(12)
+    H, W, D, zd = 80, 192, 16, 8
+    L = np.kron(rng.randint(0, 256, size=(H // 4, W // 4, 3)), np.ones((4, 4, 1))).astype(np.uint8)
+    R = np.roll(L, -2, axis=1).copy()
+    R[:, 40:90] = rng.randint(0, 256, size=(H, 50, 3))  # an unmatched band -> lots of L/R outliers
+    sbs = np.ascontiguousarray(np.concatenate([L, R], axis=1))
+    p = dev.FrameParams(num_disp=D, zero_disp=zd, usd=17, lsd=8, thresh_s=5, thresh_h=0.1)
+    dl = torch.zeros(H, W, dtype=torch.float32, device="cuda")
+    dr = torch.zeros_like(dl)
+    out = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+    dev.d_adcensus_stm(torch.from_numpy(sbs).cuda(), dl, dr, out, p, stages=2)
+    torch.cuda.synchronize()
+    want = orc.adcensus_stm(sbs, H, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd, p.usd,
+                            p.lsd, p.thresh_s, p.thresh_h)
+    assert (want["wta_l"] != want["disp_l"]).any()  # refinement really changed something
+    assert np.array_equal(dl.cpu().numpy(), want["disp_l"]) and np.array_equal(dr.cpu().numpy(), want["disp_r"])
+
+
+def test_4k_d256_properties(gpu_ready):
+    """BASELINE config 5 shape on one GPU (3840x2160, D=256): 25 GB of cost volumes through the fused pipeline.
+    Size-independent checks: fused pipeline == un-fused per-stage device chain (bit for bit), disparity range,
+    and an identical pair yields offsets <= 0 everywhere."""
+    import torch
+    from stm_amd import device_api as dev, synth
+    H, W, D, zd = 2160, 3840, 256, 128
+    sbs, _ = synth.sbs_frame(H, W, D, zd)
+    p = dev.FrameParams(num_disp=D, zero_disp=zd)
+    d_sbs = torch.from_numpy(sbs).cuda()
+    dl = torch.zeros(H, W, dtype=torch.float32, device="cuda")
+    dr = torch.zeros_like(dl)
+    out = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+    dev.d_adcensus_stm(d_sbs, dl, dr, out, p, stages=1)
+    torch.cuda.synchronize()
+    assert float(dl.min()) >= -zd and float(dl.max()) <= D - 1 - zd
+    import stm_amd
+    stm_amd.lib().stm_release_workspace()
+    dL, dR = d_sbs[:, :W].contiguous(), d_sbs[:, W:].contiguous()
+    slab = torch.zeros(2, D, H, W, dtype=torch.float32, device="cuda")
+    tab_l, tab_r = dev.d_ci_adcensus(dL, dR, slab, p.ad_coeff, p.census_coeff, D, zd)
+    scratch = torch.zeros(D, H, W, dtype=torch.float32, device="cuda")
+    cross = torch.zeros(4, H, W, dtype=torch.uint8, device="cuda")
+    dev.d_ca_cross(dL, tab_l, scratch, cross, p.ucd, p.lcd, p.usd, p.lsd, D)
+    d2 = torch.zeros_like(dl)
+    dev.d_dc_wta(tab_l, d2, D, zd)
+    torch.cuda.synchronize()
+    assert torch.equal(dl, d2)
+    del slab, scratch
+    sbs2 = np.ascontiguousarray(np.concatenate([sbs[:, :W], sbs[:, :W]], axis=1))
+    dev.d_adcensus_stm(torch.from_numpy(sbs2).cuda(), dl, dr, out, p, stages=1)
+    torch.cuda.synchronize()
+    assert float(dl.max()) <= 0 and float(dr.max()) <= 0
+    stm_amd.lib().stm_release_workspace()
+
+
+def test_error_mode_records_instead_of_exiting(gpu_ready, stm):
+    """cuda_utils.h:12-21 semantics (exit) are the default; mode 1 records the message and returns."""
+    from stm_amd import host_api
+    lib = stm.lib()
+    lib.stm_set_error_mode(1)
+    try:
+        L = np.zeros((2, 8200, 3), np.uint8)
+        cost = np.zeros((1, 2, 8200), np.float32)
+        host_api.ca_cross(L, cost, 6.0, 20.0, 3, 1)  # num_cols > 8192 is rejected by the row-tile kernel
+        assert b"8192" in lib.stm_last_error()
+    finally:
+        lib.stm_set_error_mode(0)
