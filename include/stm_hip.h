@@ -177,6 +177,40 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
                         float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
                         int thresh_s, float thresh_h, int stages);
 
+/* Reduced-resolution disparity: d_io.h:42-52 adcensus_stm_2 (d_io.cu:240-508).  The pair is
+ * bilinearly reduced to num_rows_disp x num_cols_disp, matched there, and the disparity maps are scaled back up
+ * by 1/disp_scale before the views are rendered at full resolution.  `angle` is float (A-Q24). */
+void stm_adcensus_stm_2(unsigned char *img_sbs, float *disp_l, float *disp_r, unsigned char *interlaced,
+                        int num_rows, int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out,
+                        int num_rows_disp, int num_cols_disp, int elem_sz, float disp_scale,
+                        int num_views, float angle, int num_disp, int zero_disp,
+                        float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
+                        int thresh_s, float thresh_h);
+void stm_d_adcensus_stm_2(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp_r, unsigned char *d_interlaced,
+                          int num_rows, int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out,
+                          int num_rows_disp, int num_cols_disp, int elem_sz, float disp_scale,
+                          int num_views, float angle, int num_disp, int zero_disp,
+                          float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
+                          int thresh_s, float thresh_h);
+/* d_tx_scale.h:17-18  d_tx_scale (d_tx_scale.cu:83-121): bilinear image resize; HOST pointers despite the name */
+void stm_d_tx_scale(unsigned char *img_in, unsigned char *img_out, int in_rows, int in_cols, int out_rows, int out_cols,
+                    int elem_sz);
+
+/* ------------------------------------------------- frame sequences */
+/* The reference's video loop (video_io.cpp:144-165) calls adcensus_stm once per decoded frame, serialising upload,
+ * compute and download.  A frame stream keeps the same per-frame contract (one side-by-side frame in; disp_l,
+ * disp_r and the interlaced frame out, in submission order) over double-buffered pinned/device buffers and three
+ * HIP streams, so frame k+1 uploads and frame k-1 downloads while frame k computes.  Parameters as adcensus_stm. */
+void *stm_stream_create(int num_rows, int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out, int elem_sz,
+                        int num_views, float angle, int num_disp, int zero_disp, float ad_coeff, float census_coeff,
+                        float ucd, float lcd, int usd, int lsd, int thresh_s, float thresh_h);
+/* stages the next frame (the caller's buffer is reusable on return); at most two frames in flight.
+ * Returns the frame index, or -1 if both slots are uncollected. */
+long  stm_stream_submit(void *stream, const unsigned char *img_sbs);
+/* waits for the oldest uncollected frame and copies its results out (NULL = skip).  Returns its index or -1. */
+long  stm_stream_collect(void *stream, float *disp_l, float *disp_r, unsigned char *interlaced);
+void  stm_stream_destroy(void *stream);
+
 /* ----------------------------------------------------------------- BMP I/O */
 /* image_io.cpp:95-112 reads the pair with cv::imread; these read/write the same 24-bit BMPs.
  * stm_bmp_read returns a malloc'd BGR buffer (free with stm_bmp_free) or NULL. */

@@ -295,3 +295,35 @@ def adcensus_stm(sbs, Hout, Wout, N, angle, D, zd, ad_coeff, census_coeff, ucd, 
                            thresh_s, C.c_float(thresh_h), wl.ctypes.data_as(f32p), wr.ctypes.data_as(f32p),
                            views.ctypes.data_as(u8p) if want_views else None, 1 if stop_after_wta else 0)
     return {"disp_l": dl, "disp_r": dr, "wta_l": wl, "wta_r": wr, "interlaced": inter, "views": views}
+
+
+def tx_scale_bilinear(img, out_rows, out_cols):
+    H, W, E = img.shape
+    img, pi = _u8(img)
+    out = np.zeros((out_rows, out_cols, E), np.uint8)
+    lib().orc_tx_scale_bilinear(pi, out.ctypes.data_as(u8p), H, W, out_rows, out_cols, E)
+    return out
+
+
+def tx_disp_scale(disp, out_rows, out_cols, scale):
+    h, w = disp.shape
+    disp, pd = _f32(disp)
+    out = np.zeros((out_rows, out_cols), np.float32)
+    lib().orc_tx_disp_scale(out.ctypes.data_as(f32p), pd, out_rows, out_cols, h, w, C.c_float(scale))
+    return out
+
+
+def adcensus_stm_2(sbs, Hout, Wout, h, w, disp_scale, N, angle, D, zd, ad_coeff, census_coeff, ucd, lcd, usd, lsd,
+                   thresh_s, thresh_h):
+    """Reduced-resolution frame pipeline (d_io.cu:240-508)."""
+    H, Wsbs, E = sbs.shape
+    W = Wsbs // 2
+    sbs, ps = _u8(sbs)
+    dl = np.zeros((H, W), np.float32)
+    dr = np.zeros((H, W), np.float32)
+    inter = np.zeros((Hout, Wout, E), np.uint8)
+    lib().orc_adcensus_stm_2(ps, dl.ctypes.data_as(f32p), dr.ctypes.data_as(f32p), inter.ctypes.data_as(u8p),
+                             H, Wsbs, W, Hout, Wout, h, w, E, C.c_float(disp_scale), N, C.c_float(angle), D, zd,
+                             C.c_float(ad_coeff), C.c_float(census_coeff), C.c_float(ucd), C.c_float(lcd), usd, lsd,
+                             thresh_s, C.c_float(thresh_h))
+    return {"disp_l": dl, "disp_r": dr, "interlaced": inter}

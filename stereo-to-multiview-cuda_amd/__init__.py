@@ -7,6 +7,7 @@ the host-side mirror of the reference's per-stage API:
   device_api  torch device tensors, device flavour (adcensus_stm call sites)
   bmp_io      the reference's img/*.bmp format without OpenCV
   synth       seeded synthetic stereo pairs
+  video       pipelined side-by-side frame sequences + writers (headless video_io.cpp)
   sharding    frame-batch sharding across GPUs (one process per GPU, torch.distributed)
 """
 from . import bmp_io  # noqa: F401

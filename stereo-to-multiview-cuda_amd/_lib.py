@@ -58,6 +58,13 @@ PROTOS = {
     "stm_d_demux_sbs": ([vp, vp, vp, i, i, i, i], None),
     "stm_adcensus_stm": ([u8p, f32p, f32p, u8p, i, i, i, i, i, i, i, f, i, i, f, f, f, f, i, i, i, f], None),
     "stm_d_adcensus_stm": ([vp, vp, vp, vp, i, i, i, i, i, i, i, f, i, i, f, f, f, f, i, i, i, f, i], None),
+    "stm_adcensus_stm_2": ([u8p, f32p, f32p, u8p, i, i, i, i, i, i, i, i, f, i, f, i, i, f, f, f, f, i, i, i, f], None),
+    "stm_d_adcensus_stm_2": ([vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, f, i, i, f, f, f, f, i, i, i, f], None),
+    "stm_d_tx_scale": ([u8p, u8p, i, i, i, i, i], None),
+    "stm_stream_create": ([i, i, i, i, i, i, i, f, i, i, f, f, f, f, i, i, i, f], C.c_void_p),
+    "stm_stream_submit": ([C.c_void_p, u8p], C.c_long),
+    "stm_stream_collect": ([C.c_void_p, f32p, f32p, u8p], C.c_long),
+    "stm_stream_destroy": ([C.c_void_p], None),
     "stm_bmp_read": ([C.c_char_p, C.POINTER(i), C.POINTER(i)], C.c_void_p),
     "stm_bmp_write": ([C.c_char_p, u8p, i, i], i),
     "stm_bmp_free": ([C.c_void_p], None),

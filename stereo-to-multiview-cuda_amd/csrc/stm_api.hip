@@ -480,32 +480,32 @@ void stm_d_demux_sbs(unsigned char *d_img_l, unsigned char *d_img_r, unsigned ch
     launch_demux_sbs(d_img_l, d_img_r, d_img_sbs, num_rows, num_cols_sbs, num_cols_out, elem_sz);
 }
 
+} // extern "C"
+
 // =============================================================== whole frame
 // adcensus_stm, d_io.cu:7-238: demux -> cost init -> aggregation (L, R) -> WTA -> DCC -> IRV x5 ->
 // bilateral(7,5,10) -> hit maps -> bleed(1) -> masks -> N-2 synthesised views -> interlace.
 // Differences in mechanics (not in results): one cached workspace instead of ~35 cudaMalloc/cudaFree,
-// no host synchronisation inside the frame, the last aggregation pass is fused with WTA, the mask
-// blur G(1 - maskR) is computed once per frame instead of once per view (it does not depend on the view).
-void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp_r, unsigned char *d_interlaced,
-                        int num_rows, int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out, int elem_sz,
-                        int num_views, float angle, int num_disp, int zero_disp, float ad_coeff, float census_coeff,
-                        float ucd, float lcd, int usd, int lsd, int thresh_s, float thresh_h, int stages)
+// no host synchronisation inside the frame, quad-interleaved volumes, the last aggregation pass is fused
+// with WTA, both views share the arms / IRV launches, the mask blur G(1 - maskR) is computed once per frame
+// instead of once per view (it does not depend on the view).
+namespace {
+
+// cost init .. WTA (.. DCC/IRV/bilateral when `refine`) on one rectified pair already split into L / R
+void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arms &al, Arms &ar, int H, int W, int elem_sz,
+                     int D, int zero_disp, float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
+                     int thresh_s, float thresh_h, bool refine)
 {
-    const int H = num_rows, W = num_cols, D = num_disp, N = num_views;
-    const size_t HW = (size_t)H * W, IMG = HW * elem_sz;
+    const size_t HW = (size_t)H * W;
     const int NQ = (D + 3) / 4;
     const size_t V = HW * NQ * 4; // volumes are kept quad-interleaved (float4 [NQ][H][W]) inside the frame
-    Workspace::begin(3 * V * 4 + (size_t)(N + 2) * IMG + 64 * HW + (1u << 20));
-
-    u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
-    launch_demux_sbs(img_l, img_r, d_img_sbs, H, num_cols_sbs, W, elem_sz);
-
     float *cost = Workspace::get<float>(2 * V), *scratch = Workspace::get<float>(V);
     uint32_t *pk_l = Workspace::get<uint32_t>(HW), *pk_r = Workspace::get<uint32_t>(HW);
     Vol cl = vol_quads(cost, HW), cr = vol_quads(cost + V, HW), sc = vol_quads(scratch, HW);
     core_ci(img_l, img_r, cl, cr, pk_l, pk_r, ad_coeff, census_coeff, D, zero_disp, H, W, elem_sz);
 
-    Arms al = carve_arms(HW), ar = carve_arms(HW);
+    al = carve_arms(HW);
+    ar = carve_arms(HW);
     {
         const uint32_t *pk[2] = {pk_l, pk_r};
         u8 *u[2] = {al.up, ar.up}, *d[2] = {al.down, ar.down}, *l[2] = {al.left, ar.left}, *r[2] = {al.right, ar.right};
@@ -513,7 +513,7 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
     }
     core_agg_wta(cl, sc, al, d_disp_l, D, zero_disp, H, W, usd);
     core_agg_wta(cr, sc, ar, d_disp_r, D, zero_disp, H, W, usd);
-    if (stages < 2) return;
+    if (!refine) return;
 
     u8 *outl_l = Workspace::get<u8>(HW), *outl_r = Workspace::get<u8>(HW), *hit_l = Workspace::get<u8>(HW), *hit_r = Workspace::get<u8>(HW);
     STM_CHECK(hipMemsetAsync(outl_l, 0, HW, stream())); // d_io.cu:138-141
@@ -527,8 +527,13 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
     }
     core_bilateral(d_disp_l, 7, 5.0f, 10.0f, H, W, D); // :150
     core_bilateral(d_disp_r, 7, 5.0f, 10.0f, H, W, D); // :151
-    if (stages < 3) return;
+}
 
+// hit maps -> bleed -> masks -> N-2 views -> interlace (d_io.cu:160-205)
+void frame_render(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, u8 *d_interlaced, int H, int W, int Hout, int Wout,
+                  int elem_sz, int N, float angle)
+{
+    const size_t HW = (size_t)H * W, IMG = HW * elem_sz;
     u8 *occl_l = Workspace::get<u8>(HW), *occl_r = Workspace::get<u8>(HW), *tmp8 = Workspace::get<u8>(HW);
     launch_occl(occl_l, occl_r, d_disp_l, d_disp_r, H, W); // :165
     launch_bleed(occl_l, tmp8, 1, H, W);                   // :167
@@ -548,7 +553,93 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
     // view table built on the device (no host memory involved, so nothing to keep alive or synchronise)
     u8 **dv = Workspace::get<u8 *>(N);
     launch_view_table(dv, img_r, img_l, views_mem, IMG, N);
-    core_mux((const u8 *const *)dv, d_interlaced, N, angle, H, W, num_rows_out, num_cols_out, elem_sz, 2); // :203
+    core_mux((const u8 *const *)dv, d_interlaced, N, angle, H, W, Hout, Wout, elem_sz, 2); // :203
+}
+
+} // namespace
+
+extern "C" {
+
+void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp_r, unsigned char *d_interlaced,
+                        int num_rows, int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out, int elem_sz,
+                        int num_views, float angle, int num_disp, int zero_disp, float ad_coeff, float census_coeff,
+                        float ucd, float lcd, int usd, int lsd, int thresh_s, float thresh_h, int stages)
+{
+    const int H = num_rows, W = num_cols, N = num_views;
+    const size_t HW = (size_t)H * W, IMG = HW * elem_sz;
+    const size_t V = HW * (size_t)((num_disp + 3) / 4) * 4;
+    Workspace::begin(3 * V * 4 + (size_t)(N + 2) * IMG + 96 * HW + (1u << 20));
+    u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
+    launch_demux_sbs(img_l, img_r, d_img_sbs, H, num_cols_sbs, W, elem_sz);
+    Arms al, ar;
+    frame_disparity(img_l, img_r, d_disp_l, d_disp_r, al, ar, H, W, elem_sz, num_disp, zero_disp, ad_coeff, census_coeff, ucd,
+                    lcd, usd, lsd, thresh_s, thresh_h, stages >= 2);
+    if (stages < 3) return;
+    frame_render(img_l, img_r, d_disp_l, d_disp_r, d_interlaced, H, W, num_rows_out, num_cols_out, elem_sz, N, angle);
+}
+
+// adcensus_stm_2, d_io.cu:240-508: the disparity is computed on a bilinearly reduced pair
+// (num_rows_disp x num_cols_disp, tx_scale_bilinear_kernel :302-304), scaled back up with
+// tx_disp_scale_kernel(1/disp_scale) (:415-417), then the views are rendered at full resolution.
+void stm_d_adcensus_stm_2(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp_r, unsigned char *d_interlaced,
+                          int num_rows, int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out,
+                          int num_rows_disp, int num_cols_disp, int elem_sz, float disp_scale, int num_views, float angle,
+                          int num_disp, int zero_disp, float ad_coeff, float census_coeff, float ucd, float lcd, int usd,
+                          int lsd, int thresh_s, float thresh_h)
+{
+    const int H = num_rows, W = num_cols, h = num_rows_disp, w = num_cols_disp, N = num_views;
+    const size_t HW = (size_t)H * W, IMG = HW * elem_sz, hw = (size_t)h * w;
+    const size_t V = hw * (size_t)((num_disp + 3) / 4) * 4;
+    Workspace::begin(3 * V * 4 + (size_t)(N + 4) * IMG + 96 * HW + 8 * hw + (1u << 20));
+    u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
+    launch_demux_sbs(img_l, img_r, d_img_sbs, H, num_cols_sbs, W, elem_sz);
+    u8 *low_l = Workspace::get<u8>(hw * elem_sz), *low_r = Workspace::get<u8>(hw * elem_sz);
+    launch_scale_bilinear(img_l, low_l, H, W, h, w, elem_sz);
+    launch_scale_bilinear(img_r, low_r, H, W, h, w, elem_sz);
+    float *low_dl = Workspace::get<float>(hw), *low_dr = Workspace::get<float>(hw);
+    Arms al, ar;
+    frame_disparity(low_l, low_r, low_dl, low_dr, al, ar, h, w, elem_sz, num_disp, zero_disp, ad_coeff, census_coeff, ucd, lcd,
+                    usd, lsd, thresh_s, thresh_h, true);
+    const float up = 1.0f / disp_scale; // :415
+    launch_disp_scale(d_disp_l, low_dl, H, W, h, w, up);
+    launch_disp_scale(d_disp_r, low_dr, H, W, h, w, up);
+    frame_render(img_l, img_r, d_disp_l, d_disp_r, d_interlaced, H, W, num_rows_out, num_cols_out, elem_sz, N, angle);
+}
+
+void stm_adcensus_stm_2(unsigned char *img_sbs, float *disp_l, float *disp_r, unsigned char *interlaced, int num_rows,
+                        int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out, int num_rows_disp,
+                        int num_cols_disp, int elem_sz, float disp_scale, int num_views, float angle, int num_disp,
+                        int zero_disp, float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
+                        int thresh_s, float thresh_h)
+{
+    size_t HW = (size_t)num_rows * num_cols, sbs_sz = (size_t)num_rows * num_cols_sbs * elem_sz;
+    size_t out_sz = (size_t)num_rows_out * num_cols_out * elem_sz;
+    u8 *d_sbs, *d_out;
+    float *d_dl, *d_dr;
+    STM_CHECK(hipMalloc((void **)&d_sbs, sbs_sz));
+    STM_CHECK(hipMalloc((void **)&d_out, out_sz));
+    STM_CHECK(hipMalloc((void **)&d_dl, HW * 4));
+    STM_CHECK(hipMalloc((void **)&d_dr, HW * 4));
+    STM_CHECK(hipMemcpyAsync(d_sbs, img_sbs, sbs_sz, hipMemcpyHostToDevice, stream()));
+    STM_CHECK(hipMemsetAsync(d_out, 0, out_sz, stream()));
+    stm_d_adcensus_stm_2(d_sbs, d_dl, d_dr, d_out, num_rows, num_cols_sbs, num_cols, num_rows_out, num_cols_out, num_rows_disp,
+                         num_cols_disp, elem_sz, disp_scale, num_views, angle, num_disp, zero_disp, ad_coeff, census_coeff, ucd,
+                         lcd, usd, lsd, thresh_s, thresh_h);
+    down(disp_l, d_dl, HW); down(disp_r, d_dr, HW); down(interlaced, d_out, out_sz);
+    sync();
+    STM_CHECK(hipFree(d_sbs)); STM_CHECK(hipFree(d_out)); STM_CHECK(hipFree(d_dl)); STM_CHECK(hipFree(d_dr));
+}
+
+// d_tx_scale.h:17-18  d_tx_scale (d_tx_scale.cu:83-121): despite the d_ prefix it takes HOST pointers
+void stm_d_tx_scale(unsigned char *img_in, unsigned char *img_out, int in_rows, int in_cols, int out_rows, int out_cols,
+                    int elem_sz)
+{
+    size_t in_sz = (size_t)in_rows * in_cols * elem_sz, out_sz = (size_t)out_rows * out_cols * elem_sz;
+    Workspace::begin(in_sz + out_sz + 4096);
+    u8 *di = up(img_in, in_sz), *dout = Workspace::get<u8>(out_sz);
+    launch_scale_bilinear(di, dout, in_rows, in_cols, out_rows, out_cols, elem_sz);
+    down(img_out, dout, out_sz);
+    sync();
 }
 
 void stm_adcensus_stm(unsigned char *img_sbs, float *disp_l, float *disp_r, unsigned char *interlaced, int num_rows,

@@ -119,6 +119,8 @@ void launch_occl_to_mask(float *mask_l, float *mask_r, const u8 *occl_l, const u
 void launch_view_synth(u8 *out, const u8 *img_l, const u8 *img_r, const float *disp_l, const float *disp_r,
                        const float *mask_l, const float *mask_r, const float *blend, float shift, int H, int W, int elem_sz);
 void launch_fwarp(u8 *out, const u8 *img, const float *disp, float shift, unsigned long long *keys, int H, int W, int elem_sz);
+void launch_scale_bilinear(const u8 *in, u8 *out, int in_rows, int in_cols, int out_rows, int out_cols, int elem_sz);
+void launch_disp_scale(float *out, const float *in, int out_rows, int out_cols, int in_rows, int in_cols, float disp_scale);
 void launch_view_table(u8 **tab, u8 *first, u8 *last, u8 *mem, size_t stride, int N);
 void launch_mux(const u8 *const *d_views, u8 *out, int N, float y_interval, float inv_y_interval, int ymod,
                 int Hin, int Win, int Hout, int Wout, int elem_sz, int variant);

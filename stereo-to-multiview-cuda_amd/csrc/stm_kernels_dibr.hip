@@ -188,6 +188,64 @@ void launch_view_table(u8 **tab, u8 *first, u8 *last, u8 *mem, size_t stride, in
     STM_CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------ bilinear resampling (reduced-resolution mode)
+__device__ __forceinline__ u8 bilinear_u8(const u8 *__restrict__ data, int elem_sz, int off, float cx, float cy, int width, int height);
+
+// tx_scale_bilinear_kernel, d_tx_scale.cu:30-52
+__global__ __launch_bounds__(256) void stm_k_scale_bilinear(const u8 *__restrict__ in, u8 *__restrict__ out, int in_rows,
+                                                            int in_cols, int out_rows, int out_cols, int elem_sz)
+{
+    int gx = blockIdx.x * 256 + threadIdx.x, gy = blockIdx.y;
+    if (gx >= out_cols) return;
+    float xs = ((float)gx / (float)out_cols) * (float)in_cols;
+    xs = fminf(fmaxf(xs, 0.0f), (float)(in_cols - 1));
+    float ys = ((float)gy / (float)out_rows) * (float)in_rows;
+    ys = fminf(fmaxf(ys, 0.0f), (float)(in_rows - 1));
+    size_t o = ((size_t)gx + (size_t)gy * out_cols) * elem_sz;
+    out[o + 0] = bilinear_u8(in, elem_sz, 0, xs, ys, in_cols, in_rows);
+    out[o + 1] = bilinear_u8(in, elem_sz, 1, xs, ys, in_cols, in_rows);
+    out[o + 2] = bilinear_u8(in, elem_sz, 2, xs, ys, in_cols, in_rows);
+}
+void launch_scale_bilinear(const u8 *in, u8 *out, int in_rows, int in_cols, int out_rows, int out_cols, int elem_sz)
+{
+    hipLaunchKernelGGL(stm_k_scale_bilinear, dim3(cdiv(out_cols, 256), out_rows), dim3(256), 0, stream(), in, out, in_rows,
+                       in_cols, out_rows, out_cols, elem_sz);
+    STM_CHECK_LAUNCH();
+}
+
+// tx_disp_scale_kernel + alu_bilinear_interp_f, d_tx_scale.cu:8-28, d_alu.cu:17-43
+__global__ __launch_bounds__(256) void stm_k_disp_scale(float *__restrict__ out, const float *__restrict__ in, int out_rows,
+                                                        int out_cols, int in_rows, int in_cols, float disp_scale)
+{
+    int tx = blockIdx.x * 256 + threadIdx.x, ty = blockIdx.y;
+    if (tx >= out_cols) return;
+    float xs = ((float)tx / (float)out_cols) * (float)in_cols;
+    xs = fminf(fmaxf(xs, 0.0f), (float)(in_cols - 1));
+    float ys = ((float)ty / (float)out_rows) * (float)in_rows;
+    ys = fminf(fmaxf(ys, 0.0f), (float)(in_rows - 1));
+    int x0 = (int)floorf(xs), y0 = (int)floorf(ys);
+    int x1 = min(x0 + 1, in_cols - 1), y1 = min(y0 + 1, in_rows - 1);
+    float wx = xs - (float)x0, wy = ys - (float)y0;
+    float v00 = in[(size_t)x0 + (size_t)y0 * in_cols], v01 = in[(size_t)x1 + (size_t)y0 * in_cols];
+    float v10 = in[(size_t)x0 + (size_t)y1 * in_cols], v11 = in[(size_t)x1 + (size_t)y1 * in_cols];
+    float a = v00 * (1.0f - wx);
+    float b = v01 * wx;
+    float top = a + b;
+    a = v10 * (1.0f - wx);
+    b = v11 * wx;
+    float bot = a + b;
+    a = top * (1.0f - wy);
+    b = bot * wy;
+    float r = a + b;
+    out[(size_t)tx + (size_t)ty * out_cols] = r * disp_scale;
+}
+void launch_disp_scale(float *out, const float *in, int out_rows, int out_cols, int in_rows, int in_cols, float disp_scale)
+{
+    hipLaunchKernelGGL(stm_k_disp_scale, dim3(cdiv(out_cols, 256), out_rows), dim3(256), 0, stream(), out, in, out_rows, out_cols,
+                       in_rows, in_cols, disp_scale);
+    STM_CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------ multiview interlacer
 // fast_bilinear_interp, d_mux_multiview.cu:10-36 (floor, +1 neighbour clamped, u8 truncation)
 __device__ __forceinline__ u8 bilinear_u8(const u8 *__restrict__ data, int elem_sz, int off, float cx, float cy, int width, int height)

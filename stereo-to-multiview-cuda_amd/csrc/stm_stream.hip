@@ -1,0 +1,123 @@
+// stm_stream.hip -- pipelined side-by-side frame sequence processor.
+//
+// The reference's video loop (video_io.cpp:144-165) calls adcensus_stm once per decoded frame; every call
+// uploads the frame, computes, downloads three results and only then returns, so PCIe transfers and compute
+// never overlap.  This front end keeps the same per-frame contract (one SBS frame in; disp_l, disp_r and the
+// interlaced frame out, in submission order) but runs three HIP streams over double-buffered pinned / device
+// buffers: while frame k computes, frame k+1 is uploading and frame k-1 is downloading.
+#include "stm_common.h"
+#include "../../include/stm_hip.h"
+
+#include <string.h>
+
+namespace {
+
+struct Slot {
+    u8 *h_in = nullptr, *d_in = nullptr, *d_out = nullptr, *h_out = nullptr;
+    float *d_dl = nullptr, *d_dr = nullptr, *h_dl = nullptr, *h_dr = nullptr;
+    hipEvent_t ev_in, ev_done, ev_out;
+    bool busy = false;
+};
+
+struct FrameStream {
+    int H, Wsbs, W, Hout, Wout, E, N, D, zd, usd, lsd, thresh_s;
+    float angle, ad, ce, ucd, lcd, thresh_h;
+    size_t in_sz, out_sz, hw;
+    hipStream_t s_in, s_compute, s_out;
+    Slot slot[2];
+    long submitted = 0, collected = 0;
+};
+
+} // namespace
+
+extern "C" {
+
+void *stm_stream_create(int num_rows, int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out, int elem_sz,
+                        int num_views, float angle, int num_disp, int zero_disp, float ad_coeff, float census_coeff,
+                        float ucd, float lcd, int usd, int lsd, int thresh_s, float thresh_h)
+{
+    FrameStream *f = new FrameStream();
+    f->H = num_rows; f->Wsbs = num_cols_sbs; f->W = num_cols; f->Hout = num_rows_out; f->Wout = num_cols_out; f->E = elem_sz;
+    f->N = num_views; f->angle = angle; f->D = num_disp; f->zd = zero_disp; f->ad = ad_coeff; f->ce = census_coeff;
+    f->ucd = ucd; f->lcd = lcd; f->usd = usd; f->lsd = lsd; f->thresh_s = thresh_s; f->thresh_h = thresh_h;
+    f->in_sz = (size_t)num_rows * num_cols_sbs * elem_sz;
+    f->out_sz = (size_t)num_rows_out * num_cols_out * elem_sz;
+    f->hw = (size_t)num_rows * num_cols;
+    STM_CHECK(hipStreamCreateWithFlags(&f->s_in, hipStreamNonBlocking));
+    STM_CHECK(hipStreamCreateWithFlags(&f->s_compute, hipStreamNonBlocking));
+    STM_CHECK(hipStreamCreateWithFlags(&f->s_out, hipStreamNonBlocking));
+    for (Slot &s : f->slot) {
+        STM_CHECK(hipHostMalloc((void **)&s.h_in, f->in_sz, hipHostMallocDefault));
+        STM_CHECK(hipHostMalloc((void **)&s.h_out, f->out_sz, hipHostMallocDefault));
+        STM_CHECK(hipHostMalloc((void **)&s.h_dl, f->hw * 4, hipHostMallocDefault));
+        STM_CHECK(hipHostMalloc((void **)&s.h_dr, f->hw * 4, hipHostMallocDefault));
+        STM_CHECK(hipMalloc((void **)&s.d_in, f->in_sz));
+        STM_CHECK(hipMalloc((void **)&s.d_out, f->out_sz));
+        STM_CHECK(hipMalloc((void **)&s.d_dl, f->hw * 4));
+        STM_CHECK(hipMalloc((void **)&s.d_dr, f->hw * 4));
+        STM_CHECK(hipMemset(s.d_out, 0, f->out_sz));
+        STM_CHECK(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+        STM_CHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+        STM_CHECK(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
+    }
+    return f;
+}
+
+// Stage frame `submitted`; at most two frames may be in flight (collect the older one first).
+// Returns the frame's index, or -1 when both slots are still uncollected.
+long stm_stream_submit(void *h, const unsigned char *img_sbs)
+{
+    FrameStream *f = (FrameStream *)h;
+    Slot &s = f->slot[f->submitted & 1];
+    if (s.busy) return -1;
+    memcpy(s.h_in, img_sbs, f->in_sz); // the caller's buffer is free again when this returns (as with adcensus_stm)
+    STM_CHECK(hipMemcpyAsync(s.d_in, s.h_in, f->in_sz, hipMemcpyHostToDevice, f->s_in));
+    STM_CHECK(hipEventRecord(s.ev_in, f->s_in));
+    STM_CHECK(hipStreamWaitEvent(f->s_compute, s.ev_in, 0));
+    void *prev = stm_get_stream();
+    stm_set_stream(f->s_compute);
+    stm_d_adcensus_stm(s.d_in, s.d_dl, s.d_dr, s.d_out, f->H, f->Wsbs, f->W, f->Hout, f->Wout, f->E, f->N, f->angle, f->D, f->zd,
+                       f->ad, f->ce, f->ucd, f->lcd, f->usd, f->lsd, f->thresh_s, f->thresh_h, 3);
+    stm_set_stream(prev);
+    STM_CHECK(hipEventRecord(s.ev_done, f->s_compute));
+    STM_CHECK(hipStreamWaitEvent(f->s_out, s.ev_done, 0));
+    STM_CHECK(hipMemcpyAsync(s.h_dl, s.d_dl, f->hw * 4, hipMemcpyDeviceToHost, f->s_out));
+    STM_CHECK(hipMemcpyAsync(s.h_dr, s.d_dr, f->hw * 4, hipMemcpyDeviceToHost, f->s_out));
+    STM_CHECK(hipMemcpyAsync(s.h_out, s.d_out, f->out_sz, hipMemcpyDeviceToHost, f->s_out));
+    STM_CHECK(hipEventRecord(s.ev_out, f->s_out));
+    s.busy = true;
+    return f->submitted++;
+}
+
+// Blocks until the oldest uncollected frame is complete and copies its results out (any pointer may be NULL).
+// Returns that frame's index, or -1 when nothing is pending.
+long stm_stream_collect(void *h, float *disp_l, float *disp_r, unsigned char *interlaced)
+{
+    FrameStream *f = (FrameStream *)h;
+    if (f->collected >= f->submitted) return -1;
+    Slot &s = f->slot[f->collected & 1];
+    STM_CHECK(hipEventSynchronize(s.ev_out));
+    if (disp_l) memcpy(disp_l, s.h_dl, f->hw * 4);
+    if (disp_r) memcpy(disp_r, s.h_dr, f->hw * 4);
+    if (interlaced) memcpy(interlaced, s.h_out, f->out_sz);
+    s.busy = false;
+    return f->collected++;
+}
+
+void stm_stream_destroy(void *h)
+{
+    FrameStream *f = (FrameStream *)h;
+    if (!f) return;
+    STM_CHECK(hipStreamSynchronize(f->s_in));
+    STM_CHECK(hipStreamSynchronize(f->s_compute));
+    STM_CHECK(hipStreamSynchronize(f->s_out));
+    for (Slot &s : f->slot) {
+        STM_CHECK(hipHostFree(s.h_in)); STM_CHECK(hipHostFree(s.h_out)); STM_CHECK(hipHostFree(s.h_dl)); STM_CHECK(hipHostFree(s.h_dr));
+        STM_CHECK(hipFree(s.d_in)); STM_CHECK(hipFree(s.d_out)); STM_CHECK(hipFree(s.d_dl)); STM_CHECK(hipFree(s.d_dr));
+        STM_CHECK(hipEventDestroy(s.ev_in)); STM_CHECK(hipEventDestroy(s.ev_done)); STM_CHECK(hipEventDestroy(s.ev_out));
+    }
+    STM_CHECK(hipStreamDestroy(f->s_in)); STM_CHECK(hipStreamDestroy(f->s_compute)); STM_CHECK(hipStreamDestroy(f->s_out));
+    delete f;
+}
+
+} // extern "C"

@@ -203,6 +203,29 @@ def adcensus_stm(img_sbs, num_cols, out_rows, out_cols, num_views, angle, num_di
     return dl, dr, out
 
 
+def adcensus_stm_2(img_sbs, num_cols, out_rows, out_cols, disp_rows, disp_cols, disp_scale, num_views, angle, num_disp,
+                   zero_disp, ad_coeff, census_coeff, ucd, lcd, usd, lsd, thresh_s, thresh_h):
+    """d_io.h:42-52: disparity at reduced resolution (disp_rows x disp_cols), views at full resolution."""
+    img_sbs, ps = _u8(img_sbs)
+    H, Wsbs, E = img_sbs.shape
+    dl = np.zeros((H, num_cols), np.float32)
+    dr = np.zeros((H, num_cols), np.float32)
+    out = np.zeros((out_rows, out_cols, E), np.uint8)
+    lib().stm_adcensus_stm_2(ps, dl.ctypes.data_as(f32p), dr.ctypes.data_as(f32p), out.ctypes.data_as(u8p),
+                             H, Wsbs, num_cols, out_rows, out_cols, disp_rows, disp_cols, E, disp_scale, num_views, angle,
+                             num_disp, zero_disp, ad_coeff, census_coeff, ucd, lcd, usd, lsd, thresh_s, thresh_h)
+    return dl, dr, out
+
+
+def tx_scale(img, out_rows, out_cols):
+    """d_tx_scale.h:17-18 (bilinear resize)."""
+    img, pi = _u8(img)
+    H, W, E = img.shape
+    out = np.zeros((out_rows, out_cols, E), np.uint8)
+    lib().stm_d_tx_scale(pi, out.ctypes.data_as(u8p), H, W, out_rows, out_cols, E)
+    return out
+
+
 def bmp_read(path):
     """stm_bmp_read: the C++ twin of bmp_io.read_bmp (replaces cv::imread, image_io.cpp:95-96)."""
     h, w = C.c_int(0), C.c_int(0)

@@ -6,6 +6,8 @@ outlier classes, hit maps, views, interlaced image); float stages within 1e-4 re
 The HIP path sums windows and filter taps in the reference's order with no contraction, so the float stages
 are in fact asserted BIT-EXACT here, which is stronger than the stated tolerance.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -411,3 +413,53 @@ def test_error_mode_records_instead_of_exiting(gpu_ready, stm):
         assert b"8192" in lib.stm_last_error()
     finally:
         lib.stm_set_error_mode(0)
+
+
+# ----------------------------------------------------------------------------- reduced-resolution mode
+@pytest.mark.parametrize("H,W,h,w", [(96, 160, 48, 80), (75, 131, 40, 70)])
+def test_reduced_resolution_pipeline(api, orc, H, W, h, w):
+    """adcensus_stm_2 (d_io.cu:240-508): bilinear down-scale, match at low resolution, disparity up-scale, render."""
+    from stm_amd import synth
+    D, zd = 12, 6
+    sbs, _ = synth.sbs_frame(H, W, 2 * D, 2 * zd)
+    img = np.ascontiguousarray(sbs[:, :W])
+    assert np.array_equal(api.tx_scale(img, h, w), orc.tx_scale_bilinear(img, h, w))
+    scale = float(w) / float(W)
+    got = api.adcensus_stm_2(sbs, W, H, W, h, w, scale, 8, 18.43, D, zd, 10.0, 30.0, 6.0, 20.0, 9, 4, 10, 0.2)
+    want = orc.adcensus_stm_2(sbs, H, W, h, w, scale, 8, 18.43, D, zd, 10.0, 30.0, 6.0, 20.0, 9, 4, 10, 0.2)
+    assert np.array_equal(got[0], want["disp_l"]) and np.array_equal(got[1], want["disp_r"])
+    assert np.array_equal(got[2], want["interlaced"])
+
+
+# ----------------------------------------------------------------------------- SURVEY 8f row N1: frame sequences
+def test_frame_stream_matches_per_frame_calls(gpu_ready, orc):
+    """The pipelined sequence front end returns, in order, exactly what adcensus_stm returns frame by frame."""
+    from stm_amd import device_api as dev, host_api, synth, video
+    H, W, D, zd = 64, 96, 8, 4
+    p = dev.FrameParams(num_disp=D, zero_disp=zd, usd=9, lsd=4)
+    frames = [synth.sbs_frame(H, W, D, zd, seed=synth.SEED + k)[0] for k in range(5)]
+    got = list(video.process_sequence(iter(frames), p))
+    assert [g[0] for g in got] == [0, 1, 2, 3, 4]
+    for k, f in enumerate(frames):
+        dl, dr, out = host_api.adcensus_stm(f, W, H, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd,
+                                            p.usd, p.lsd, p.thresh_s, p.thresh_h)
+        assert np.array_equal(got[k][1], dl) and np.array_equal(got[k][2], dr) and np.array_equal(got[k][3], out)
+    want = orc.adcensus_stm(frames[3], H, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd, p.usd,
+                            p.lsd, p.thresh_s, p.thresh_h)
+    assert np.array_equal(got[3][3], want["interlaced"]) and np.array_equal(got[3][1], want["disp_l"])
+
+
+def test_video_cli_roundtrip(gpu_ready, tmp_path):
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from stm_amd import bmp_io, synth
+    H, W, D, zd = 48, 64, 8, 4
+    for k in range(3):
+        bmp_io.write_bmp(str(tmp_path / ("f%03d.bmp" % k)), synth.sbs_frame(H, W, D, zd, seed=synth.SEED + k)[0])
+    out = tmp_path / "o"
+    args = [sys.executable, os.path.join(ROOT, "tools", "stm_video.py"), str(tmp_path), "8", "18.43", str(W), str(H), str(D), str(zd),
+            "10", "30", "6", "20", "9", "4", "20", "0.4", str(out)]
+    subprocess.check_call(args)
+    assert sorted(os.listdir(out)) == sorted(["%s_%05d.bmp" % (n, k) for n in ("interlaced", "disp_l", "disp_r") for k in range(3)])
+    assert bmp_io.read_bmp(str(out / "interlaced_00001.bmp")).shape == (H, W, 3)
