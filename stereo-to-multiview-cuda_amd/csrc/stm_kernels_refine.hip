@@ -114,12 +114,6 @@ constexpr int IV_WAVES = 4;     // waves per block
 constexpr int IV_BLOCKS = 1024; // persistent grid per view
 constexpr int IV_U = 4;         // row pairs whose loads are in flight together
 
-// value held by lane (j & 63) of v0 (j < 64) or v1 (j >= 64), for a wave-uniform j
-__device__ __forceinline__ int irv_row_value(int v0, int v1, int j)
-{
-    return j < 64 ? __builtin_amdgcn_readlane(v0, j) : __builtin_amdgcn_readlane(v1, j - 64);
-}
-
 // one LDS atomic per voting lane: equal bins serialise inside the LDS atomic unit (<= 64 cycles), which beats a
 // ballot-merge loop whenever a step sees more than a couple of distinct disparities -- and outliers sit exactly
 // where the disparity map is noisy
@@ -175,32 +169,37 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
         const int y_top = gy - cu;
         int total = 0;
         for (int jb = 0; jb < nrows; jb += 128) { // 128 rows per outer step covers every usd <= 63 in one go
-            // horizontal arms of the region's rows, fetched once: lane <-> rows jb+lane and jb+64+lane
-            int cl0 = 0, w0 = 0, cl1 = 0, w1 = 0;
+            // horizontal arms of the region's rows, fetched once and packed into ONE register per lane:
+            // bits 0-15 = row jb+lane, bits 16-31 = row jb+64+lane, each (armL | (armL+armR+1) << 8 ... as 8+9 bits)
+            uint32_t packed = 0; // per row: armL in 7 bits is not enough for usd <= 255, so: low byte armL, next 9 bits width
+            uint32_t packed_hi = 0;
             if (jb + lane < nrows) {
                 const int q = (y_top + jb + lane) * W + gx;
-                cl0 = aL[q];
-                w0 = cl0 + (int)aR[q] + 1; // x-armL .. x+armR inclusive
+                const uint32_t cl = aL[q];
+                packed = cl | ((cl + (uint32_t)aR[q] + 1u) << 8); // armL | width << 8  (width <= 511)
             }
             if (jb + 64 + lane < nrows) {
                 const int q = (y_top + jb + 64 + lane) * W + gx;
-                cl1 = aL[q];
-                w1 = cl1 + (int)aR[q] + 1;
+                const uint32_t cl = aL[q];
+                packed_hi = cl | ((cl + (uint32_t)aR[q] + 1u) << 8);
             }
             const int jend = min(nrows - jb, 128);
             for (int j0 = 0; j0 < jend; j0 += IV_U) {
                 u8 o[IV_U];
                 float dv[IV_U];
                 int wd[IV_U], base[IV_U];
+                int wmax = 0;
 #pragma unroll
                 for (int u = 0; u < IV_U; ++u) { // first 64 pixels of IV_U rows: all loads issued before any is consumed
-                    const int j = min(j0 + u, 127);
-                    int cl = irv_row_value(cl0, cl1, j), w = irv_row_value(w0, w1, j);
-                    if (j0 + u >= jend) w = 0;
+                    const int j = j0 + u; // wave-uniform
+                    const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)((j & 64) ? packed_hi : packed), j & 63);
+                    const int cl = (int)(pk & 0xff);
+                    int w = j < jend ? (int)(pk >> 8) : 0;
                     int xs = gx - cl; // scalar; clamp the segment into the row (no-op for consistent arms)
                     if (xs < 0) { w += xs; xs = 0; }
                     w = min(w, W - xs);
                     wd[u] = w;
+                    wmax = max(wmax, w);
                     base[u] = (y_top + jb + j) * W + xs;
                     o[u] = 1;
                     dv[u] = 0.f;
@@ -218,15 +217,17 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
                     }
                     irv_tally(code, hist, total);
                 }
+                if (wmax > 64) { // segments wider than 64 pixels (arm sum >= 64): rare
 #pragma unroll
-                for (int u = 0; u < IV_U; ++u) { // segments wider than 64 pixels (arm sum >= 64): rare
-                    for (int c0 = 64; c0 < wd[u]; c0 += 64) {
-                        int code = -1;
-                        if (c0 + lane < wd[u] && outl[base[u] + c0 + lane] == 0) {
-                            const int b = (int)disp[base[u] + c0 + lane] + zd;
-                            code = (b >= 0 && b < nb) ? b : -2;
+                    for (int u = 0; u < IV_U; ++u) {
+                        for (int c0 = 64; c0 < wd[u]; c0 += 64) {
+                            int code = -1;
+                            if (c0 + lane < wd[u] && outl[base[u] + c0 + lane] == 0) {
+                                const int b = (int)disp[base[u] + c0 + lane] + zd;
+                                code = (b >= 0 && b < nb) ? b : -2;
+                            }
+                            irv_tally(code, hist, total);
                         }
-                        irv_tally(code, hist, total);
                     }
                 }
             }
