@@ -25,11 +25,17 @@
 namespace stm {
 
 // ------------------------------------------------------------------ cross arms
-__device__ __forceinline__ int mad_bgrx(uint32_t a, uint32_t b)
+// max over B,G,R of |difference| between two packed pixels, from their per-channel masked copies
+// (x & 0xff, x & 0xff00, x & 0xff0000): |a_ch - b_ch| is one v_sad_u8 on operands whose other bytes are zero.
+struct Px3 {
+    uint32_t b, g, r;
+};
+__device__ __forceinline__ Px3 split_bgrx(uint32_t p) { return Px3{p & 0xffu, p & 0xff00u, p & 0xff0000u}; }
+__device__ __forceinline__ int mad_px3(const Px3 &x, const Px3 &y)
 {
-    int d0 = abs((int)(a & 0xff) - (int)(b & 0xff));
-    int d1 = abs((int)((a >> 8) & 0xff) - (int)((b >> 8) & 0xff));
-    int d2 = abs((int)(a >> 16) - (int)(b >> 16));
+    const int d0 = (int)__builtin_amdgcn_sad_u8(x.b, y.b, 0u);
+    const int d1 = (int)__builtin_amdgcn_sad_u8(x.g, y.g, 0u);
+    const int d2 = (int)__builtin_amdgcn_sad_u8(x.r, y.r, 0u);
     return max(max(d0, d1), d2);
 }
 
@@ -39,19 +45,19 @@ __device__ __forceinline__ int mad_bgrx(uint32_t a, uint32_t b)
 // lcd, far tier when anchor-vs-current exceeds ucd.  `(float)int > float` is evaluated as int > floor(float),
 // which is the same predicate for every integer left-hand side.
 __device__ __forceinline__ int one_arm(const uint32_t *__restrict__ p, int stride, int kmax, int lsd, int t_far, int t_near,
-                                       uint32_t anchor)
+                                       const Px3 &anchor)
 {
-    uint32_t prev = anchor;
+    Px3 prev = anchor;
     int arm = 0;
     for (int k = 1; k <= kmax; ++k) {
         p += stride;
-        const uint32_t c = *p;
+        const Px3 c = split_bgrx(*p);
         arm = k;
-        const int ac = mad_bgrx(c, anchor);
+        const int ac = mad_px3(c, anchor);
         if (k > lsd) {
             if (ac > t_far) break;
         } else {
-            if (ac > t_near || mad_bgrx(c, prev) > t_near) break;
+            if (ac > t_near || mad_px3(c, prev) > t_near) break;
             prev = c;
         }
     }
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(256) void stm_k_cross_arms(ArmsArgs a, int t_far, i
     if (x >= W) return;
     const int p = y * W + x;
     const uint32_t *__restrict__ img = a.img[v] + p;
-    const uint32_t anchor = *img;
+    const Px3 anchor = split_bgrx(*img);
     a.up[v][p] = (u8)one_arm(img, -W, min(usd, y), lsd, t_far, t_near, anchor);
     a.down[v][p] = (u8)one_arm(img, W, min(usd, H - 1 - y), lsd, t_far, t_near, anchor);
     a.left[v][p] = (u8)one_arm(img, -1, min(usd, x), lsd, t_far, t_near, anchor);
