@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--disp", type=int, default=64)
-    ap.add_argument("--stages", type=int, default=3, help="1 = cost+agg+WTA (config 2), 2 = +refinement (config 3), 3 = full frame")
+    ap.add_argument("--stages", type=int, default=3, help="1 = cost+agg+WTA (config 2), 2 = +refinement (config 3), 3 = full frame; add 256 for HSLO before WTA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--agg-variant", type=int, default=0)
     return ap.parse_args()
@@ -134,7 +134,7 @@ def main():
         alg = {"agg_h": 2 * V + 2 * HW, "agg_v": 2 * V + 2 * HW, "agg_hw": V + 2 * HW + 4 * HW,
                "cost_init": 2 * V + 4 * 4 * HW}
         kern = {}
-        for name in ["agg_h", "agg_v", "agg_hw", "cost_init", "cross_arms", "irv", "bilateral", "gaussian_max",
+        for name in ["agg_h", "agg_v", "agg_hw", "cost_init", "cross_arms", "hslo", "wta", "irv", "bilateral", "gaussian_max",
                      "view_synth", "mux"]:
             n, ms = dev.prof_read(name)
             if n:
@@ -164,7 +164,8 @@ def main():
             "config": {"workload": "%dx%d synthetic stereo frame, D=%d, zd=%d, %s, one frame per GPU per step" % (
                 W, H, D, zd, {1: "cost init + cross aggregation + WTA (BASELINE config 2)",
                               2: "config 2 + DCC + IRV x5 + bilateral (config 3)",
-                              3: "full stereo->8-view frame: cost init + cross aggregation + WTA + DCC/IRV x5/bilateral + 6 DIBR views + interlacing"}[args.stages]),
+                              3: "full stereo->8-view frame: cost init + cross aggregation + WTA + DCC/IRV x5/bilateral + 6 DIBR views + interlacing"}[args.stages & 0xff]
+                + (" + scanline optimisation (HSLO) before WTA" if args.stages & 0x100 else "")),
                        "stages": args.stages, "usd": p.usd, "lsd": p.lsd, "views": p.num_views, "sharding": "frames, 1 per rank"},
             "roofline": roofline,
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern.items()},

@@ -169,7 +169,9 @@ void stm_adcensus_stm(unsigned char *img_sbs, float *disp_l, float *disp_r, unsi
 /* Device-resident frame: same pipeline, all four buffers already in HBM, nothing synchronised.
  * stages: 1 = cost init + aggregation + WTA only (BASELINE config 2);
  *         2 = + DCC / IRV x5 / bilateral          (config 3);
- *         3 = + DIBR views + interlacing           (config 4, the full adcensus_stm). */
+ *         3 = + DIBR views + interlacing           (config 4, the full adcensus_stm).
+ * OR-ing 0x100 inserts the scanline optimisation (HSLO, constants of image_io.cpp:311-313) between aggregation
+ * and WTA for both views, as Mei et al. order it; the reference never wires it in (parity unpinned). */
 void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp_r, unsigned char *d_interlaced,
                         int num_rows, int num_cols_sbs, int num_cols,
                         int num_rows_out, int num_cols_out, int elem_sz,

@@ -278,7 +278,7 @@ def demux_sbs(sbs, W):
 
 
 def adcensus_stm(sbs, Hout, Wout, N, angle, D, zd, ad_coeff, census_coeff, ucd, lcd, usd, lsd, thresh_s, thresh_h,
-                 stop_after_wta=False, want_views=False):
+                 stop_after_wta=False, want_views=False, hslo=False):
     """Whole-frame pipeline (d_io.cu:7-238).  Returns a dict of outputs."""
     H, Wsbs, E = sbs.shape
     W = Wsbs // 2
@@ -293,7 +293,7 @@ def adcensus_stm(sbs, Hout, Wout, N, angle, D, zd, ad_coeff, census_coeff, ucd, 
                            H, Wsbs, W, Hout, Wout, E, N, C.c_float(angle), D, zd,
                            C.c_float(ad_coeff), C.c_float(census_coeff), C.c_float(ucd), C.c_float(lcd), usd, lsd,
                            thresh_s, C.c_float(thresh_h), wl.ctypes.data_as(f32p), wr.ctypes.data_as(f32p),
-                           views.ctypes.data_as(u8p) if want_views else None, 1 if stop_after_wta else 0)
+                           views.ctypes.data_as(u8p) if want_views else None, (1 if stop_after_wta else 0) | (2 if hslo else 0))
     return {"disp_l": dl, "disp_r": dr, "wta_l": wl, "wta_r": wr, "interlaced": inter, "views": views}
 
 

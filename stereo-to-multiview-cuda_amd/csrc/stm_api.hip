@@ -244,10 +244,11 @@ void stm_d_dc_hslo(float **d_cost, float *d_disp, unsigned char *d_img_l, unsign
                    float H2, int num_disp, int zero_disp, int num_rows, int num_cols, int elem_sz)
 {
     size_t HW = (size_t)num_rows * num_cols;
-    Workspace::begin((size_t)num_disp * HW * 4 + 4096);
+    Workspace::begin((size_t)num_disp * HW * 4 + 8 * HW + 4096);
     float *acc = Workspace::get<float>((size_t)num_disp * HW);
+    float *avl = Workspace::get<float>(HW), *avr = Workspace::get<float>(HW);
     Vol a = vol_slab(acc, HW);
-    launch_hslo(vol_table(d_cost), a, d_img_l, d_img_r, T, H1, H2, num_disp, zero_disp, num_rows, num_cols, elem_sz);
+    launch_hslo(vol_table(d_cost), a, d_img_l, d_img_r, avl, avr, T, H1, H2, num_disp, zero_disp, num_rows, num_cols, elem_sz);
     launch_scale_volume(a, 0.25f, num_disp, num_rows, num_cols);
     launch_wta(a, d_disp, num_disp, zero_disp, num_rows, num_cols);
 }
@@ -255,12 +256,13 @@ void stm_dc_hslo(float **cost, float *disp, unsigned char *img_l, unsigned char 
                  int num_disp, int zero_disp, int num_rows, int num_cols, int elem_sz)
 {
     size_t HW = (size_t)num_rows * num_cols, V = HW * num_disp;
-    Workspace::begin(2 * V * 4 + 2 * HW * elem_sz + HW * 4 + 8192);
+    Workspace::begin(2 * V * 4 + 2 * HW * elem_sz + 3 * HW * 4 + 8192);
     float *c = up_planes(cost, num_disp, HW);
     u8 *dl = up(img_l, HW * elem_sz), *dr = up(img_r, HW * elem_sz);
     float *acc = Workspace::get<float>(V), *d = Workspace::get<float>(HW);
+    float *avl = Workspace::get<float>(HW), *avr = Workspace::get<float>(HW);
     Vol a = vol_slab(acc, HW);
-    launch_hslo(vol_slab(c, HW), a, dl, dr, T, H1, H2, num_disp, zero_disp, num_rows, num_cols, elem_sz);
+    launch_hslo(vol_slab(c, HW), a, dl, dr, avl, avr, T, H1, H2, num_disp, zero_disp, num_rows, num_cols, elem_sz);
     launch_scale_volume(a, 0.25f, num_disp, num_rows, num_cols);
     launch_wta(a, d, num_disp, zero_disp, num_rows, num_cols);
     down(disp, d, HW);
@@ -494,7 +496,7 @@ namespace {
 // cost init .. WTA (.. DCC/IRV/bilateral when `refine`) on one rectified pair already split into L / R
 void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arms &al, Arms &ar, int H, int W, int elem_sz,
                      int D, int zero_disp, float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
-                     int thresh_s, float thresh_h, bool refine)
+                     int thresh_s, float thresh_h, bool refine, bool hslo = false)
 {
     const size_t HW = (size_t)H * W;
     const int NQ = (D + 3) / 4;
@@ -511,8 +513,23 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
         u8 *u[2] = {al.up, ar.up}, *d[2] = {al.down, ar.down}, *l[2] = {al.left, ar.left}, *r[2] = {al.right, ar.right};
         launch_cross_arms2(2, pk, u, d, l, r, ucd, lcd, usd, lsd, H, W);
     }
-    core_agg_wta(cl, sc, al, d_disp_l, D, zero_disp, H, W, usd);
-    core_agg_wta(cr, sc, ar, d_disp_r, D, zero_disp, H, W, usd);
+    if (hslo) {
+        // Mei et al. 3.3: scanline optimisation of the aggregated cost, then WTA.  Penalty constants: the values the
+        // reference's (commented-out) test call uses, image_io.cpp:311-313.  Parity unpinned.
+        float *avl = Workspace::get<float>(HW), *avr = Workspace::get<float>(HW);
+        core_agg(cl, sc, al, D, H, W, usd);
+        launch_hslo(cl, sc, img_l, img_r, avl, avr, 15.0f, 1.0f, 3.0f, D, zero_disp, H, W, elem_sz);
+        launch_scale_volume(sc, 0.25f, D, H, W);
+        launch_wta(sc, d_disp_l, D, zero_disp, H, W);
+        core_agg(cr, sc, ar, D, H, W, usd);
+        // the right view's penalty rule mirrors the left one: its own image plays "left", offsets change sign
+        launch_hslo(cr, sc, img_r, img_l, avl, avr, 15.0f, 1.0f, 3.0f, D, zero_disp, H, W, elem_sz, -1);
+        launch_scale_volume(sc, 0.25f, D, H, W);
+        launch_wta(sc, d_disp_r, D, zero_disp, H, W);
+    } else {
+        core_agg_wta(cl, sc, al, d_disp_l, D, zero_disp, H, W, usd);
+        core_agg_wta(cr, sc, ar, d_disp_r, D, zero_disp, H, W, usd);
+    }
     if (!refine) return;
 
     u8 *outl_l = Workspace::get<u8>(HW), *outl_r = Workspace::get<u8>(HW), *hit_l = Workspace::get<u8>(HW), *hit_r = Workspace::get<u8>(HW);
@@ -572,8 +589,10 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
     u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
     launch_demux_sbs(img_l, img_r, d_img_sbs, H, num_cols_sbs, W, elem_sz);
     Arms al, ar;
+    const bool hslo = (stages & 0x100) != 0; // + scanline optimisation between aggregation and WTA (BASELINE config 3)
+    stages &= 0xff;
     frame_disparity(img_l, img_r, d_disp_l, d_disp_r, al, ar, H, W, elem_sz, num_disp, zero_disp, ad_coeff, census_coeff, ucd,
-                    lcd, usd, lsd, thresh_s, thresh_h, stages >= 2);
+                    lcd, usd, lsd, thresh_s, thresh_h, stages >= 2, hslo);
     if (stages < 3) return;
     frame_render(img_l, img_r, d_disp_l, d_disp_r, d_interlaced, H, W, num_rows_out, num_cols_out, elem_sz, N, angle);
 }

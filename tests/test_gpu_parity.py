@@ -463,3 +463,34 @@ def test_video_cli_roundtrip(gpu_ready, tmp_path):
     subprocess.check_call(args)
     assert sorted(os.listdir(out)) == sorted(["%s_%05d.bmp" % (n, k) for n in ("interlaced", "disp_l", "disp_r") for k in range(3)])
     assert bmp_io.read_bmp(str(out / "interlaced_00001.bmp")).shape == (H, W, 3)
+
+
+# ----------------------------------------------------------------------------- HSLO (parity unpinned: oracle-defined)
+@pytest.mark.parametrize("D,zd", [(64, 32), (100, 40), (200, 90), (5, 1)])
+def test_hslo_wave_per_line(api, orc, D, zd):
+    """One wave per scan line, lanes = hypotheses: 1, 2 and 4 values per lane (D <= 64, 128, 256) and a ragged D."""
+    L, R = rand_pair(36, 70, 19 + D)
+    rng = np.random.RandomState(D)
+    c = (rng.random_sample((D, 36, 70)) * 3).astype(np.float32)
+    assert np.array_equal(api.dc_hslo(c, L, R, 15.0, 1.0, 3.0, zd), orc.dc_hslo(c, L, R, 15.0, 1.0, 3.0, zd))
+
+
+@pytest.mark.parametrize("stages", [1, 3])
+def test_device_frame_pipeline_with_hslo(gpu_ready, orc, stages):
+    """BASELINE config 3 ordering: aggregation -> scanline optimisation -> WTA -> DCC/IRV/bilateral (stages | 0x100)."""
+    import torch
+    from stm_amd import device_api as dev, synth
+    H, W, D, zd = 90, 200, 24, 12
+    sbs, _ = synth.sbs_frame(H, W, D, zd)
+    p = dev.FrameParams(num_disp=D, zero_disp=zd, usd=17, lsd=8)
+    dl = torch.zeros(H, W, dtype=torch.float32, device="cuda")
+    dr = torch.zeros_like(dl)
+    out = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+    dev.d_adcensus_stm(torch.from_numpy(sbs).cuda(), dl, dr, out, p, stages=stages | 0x100)
+    torch.cuda.synchronize()
+    want = orc.adcensus_stm(sbs, H, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd, p.usd,
+                            p.lsd, p.thresh_s, p.thresh_h, stop_after_wta=(stages == 1), hslo=True)
+    key = "wta" if stages == 1 else "disp"
+    assert np.array_equal(dl.cpu().numpy(), want[key + "_l"]) and np.array_equal(dr.cpu().numpy(), want[key + "_r"])
+    if stages == 3:
+        assert np.array_equal(out.cpu().numpy(), want["interlaced"])
