@@ -244,27 +244,26 @@ void stm_d_dc_hslo(float **d_cost, float *d_disp, unsigned char *d_img_l, unsign
                    float H2, int num_disp, int zero_disp, int num_rows, int num_cols, int elem_sz)
 {
     size_t HW = (size_t)num_rows * num_cols;
-    Workspace::begin((size_t)num_disp * HW * 4 + 8 * HW + 4096);
-    float *acc = Workspace::get<float>((size_t)num_disp * HW);
-    float *avl = Workspace::get<float>(HW), *avr = Workspace::get<float>(HW);
-    Vol a = vol_slab(acc, HW);
-    launch_hslo(vol_table(d_cost), a, d_img_l, d_img_r, avl, avr, T, H1, H2, num_disp, zero_disp, num_rows, num_cols, elem_sz);
-    launch_scale_volume(a, 0.25f, num_disp, num_rows, num_cols);
-    launch_wta(a, d_disp, num_disp, zero_disp, num_rows, num_cols);
+    Workspace::begin((size_t)num_disp * HW * 16 + 8 * HW + 8192);
+    Vol c = vol_table(d_cost);
+    const u8 *ia[1] = {d_img_l}, *ib[1] = {d_img_r};
+    const int os[1] = {1};
+    float *dv[1] = {d_disp};
+    launch_hslo_wta(1, &c, ia, ib, os, dv, nullptr, T, H1, H2, num_disp, zero_disp, num_rows, num_cols, elem_sz);
 }
 void stm_dc_hslo(float **cost, float *disp, unsigned char *img_l, unsigned char *img_r, float T, float H1, float H2,
                  int num_disp, int zero_disp, int num_rows, int num_cols, int elem_sz)
 {
     size_t HW = (size_t)num_rows * num_cols, V = HW * num_disp;
-    Workspace::begin(2 * V * 4 + 2 * HW * elem_sz + 3 * HW * 4 + 8192);
+    Workspace::begin(5 * V * 4 + 2 * HW * elem_sz + 3 * HW * 4 + 16384);
     float *c = up_planes(cost, num_disp, HW);
     u8 *dl = up(img_l, HW * elem_sz), *dr = up(img_r, HW * elem_sz);
-    float *acc = Workspace::get<float>(V), *d = Workspace::get<float>(HW);
-    float *avl = Workspace::get<float>(HW), *avr = Workspace::get<float>(HW);
-    Vol a = vol_slab(acc, HW);
-    launch_hslo(vol_slab(c, HW), a, dl, dr, avl, avr, T, H1, H2, num_disp, zero_disp, num_rows, num_cols, elem_sz);
-    launch_scale_volume(a, 0.25f, num_disp, num_rows, num_cols);
-    launch_wta(a, d, num_disp, zero_disp, num_rows, num_cols);
+    float *d = Workspace::get<float>(HW);
+    Vol cv = vol_slab(c, HW);
+    const u8 *ia[1] = {dl}, *ib[1] = {dr};
+    const int os[1] = {1};
+    float *dv[1] = {d};
+    launch_hslo_wta(1, &cv, ia, ib, os, dv, nullptr, T, H1, H2, num_disp, zero_disp, num_rows, num_cols, elem_sz);
     down(disp, d, HW);
     sync();
 }
@@ -516,16 +515,13 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
     if (hslo) {
         // Mei et al. 3.3: scanline optimisation of the aggregated cost, then WTA.  Penalty constants: the values the
         // reference's (commented-out) test call uses, image_io.cpp:311-313.  Parity unpinned.
-        float *avl = Workspace::get<float>(HW), *avr = Workspace::get<float>(HW);
         core_agg(cl, sc, al, D, H, W, usd);
-        launch_hslo(cl, sc, img_l, img_r, avl, avr, 15.0f, 1.0f, 3.0f, D, zero_disp, H, W, elem_sz);
-        launch_scale_volume(sc, 0.25f, D, H, W);
-        launch_wta(sc, d_disp_l, D, zero_disp, H, W);
         core_agg(cr, sc, ar, D, H, W, usd);
-        // the right view's penalty rule mirrors the left one: its own image plays "left", offsets change sign
-        launch_hslo(cr, sc, img_r, img_l, avl, avr, 15.0f, 1.0f, 3.0f, D, zero_disp, H, W, elem_sz, -1);
-        launch_scale_volume(sc, 0.25f, D, H, W);
-        launch_wta(sc, d_disp_r, D, zero_disp, H, W);
+        const Vol cv[2] = {cl, cr};
+        const u8 *ia[2] = {img_l, img_r}, *ib[2] = {img_r, img_l}; // the right view's own image plays "left"
+        const int os[2] = {1, -1};
+        float *dv[2] = {d_disp_l, d_disp_r};
+        launch_hslo_wta(2, cv, ia, ib, os, dv, nullptr, 15.0f, 1.0f, 3.0f, D, zero_disp, H, W, elem_sz);
     } else {
         core_agg_wta(cl, sc, al, d_disp_l, D, zero_disp, H, W, usd);
         core_agg_wta(cr, sc, ar, d_disp_r, D, zero_disp, H, W, usd);
@@ -585,7 +581,7 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
     const int H = num_rows, W = num_cols, N = num_views;
     const size_t HW = (size_t)H * W, IMG = HW * elem_sz;
     const size_t V = HW * (size_t)((num_disp + 3) / 4) * 4;
-    Workspace::begin(3 * V * 4 + (size_t)(N + 2) * IMG + 96 * HW + (1u << 20));
+    Workspace::begin(((stages & 0x100) ? 11 : 3) * V * 4 + (size_t)(N + 2) * IMG + 112 * HW + (1u << 20));
     u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
     launch_demux_sbs(img_l, img_r, d_img_sbs, H, num_cols_sbs, W, elem_sz);
     Arms al, ar;

@@ -125,8 +125,9 @@ void launch_view_table(u8 **tab, u8 *first, u8 *last, u8 *mem, size_t stride, in
 void launch_mux(const u8 *const *d_views, u8 *out, int N, float y_interval, float inv_y_interval, int ymod,
                 int Hin, int Win, int Hout, int Wout, int elem_sz, int variant);
 // HSLO (stm_kernels_hslo.hip)
-void launch_hslo(Vol cost, Vol acc, const u8 *img_l, const u8 *img_r, float *avg_l, float *avg_r, float T, float H1, float H2,
-                 int D, int zd, int H, int W, int elem_sz, int osign = 1);
+void launch_hslo_wta(int nviews, const Vol *cost, const u8 *const *img_a, const u8 *const *img_b, const int *osign,
+                     float *const *disp, float *const *vol_out, float T, float H1, float H2, int D, int zd, int H, int W,
+                     int elem_sz);
 void launch_scale_volume(Vol v, float s, int D, int H, int W);
 
 // host-built tables (same formulas as the reference's host code; see stm_tables.cpp)
