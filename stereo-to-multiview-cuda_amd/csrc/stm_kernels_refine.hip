@@ -76,13 +76,26 @@ struct IrvArgs {
     uint32_t *list_a[2], *list_b[2]; // ping-pong outlier lists
     int *counts[2];                  // counts[v][k] = length of the list that iteration k votes on
     u8 *dirty[2];                    // dirty[v][it][tile]: a pixel of the 64x64 tile was accepted in iteration it
+    int16_t *code[2];                // per pixel: histogram bin of a reliable pixel, -1 = outlier (no vote), -2 = reliable, bin out of range
 };
 
+// vote code of one pixel: (int)disp + zero_disp is the histogram bin (d_dr_irv.cu:200-201)
+__device__ __forceinline__ int16_t irv_code(u8 outl, float disp, int zd, int nb)
+{
+    if (outl != 0) return (int16_t)-1;
+    const int b = (int)disp + zd;
+    return (b >= 0 && b < nb) ? (int16_t)b : (int16_t)-2;
+}
+
 // four pixels per thread (one dword of the u8 outlier map); one global atomic per WAVE that holds any outlier
-__global__ __launch_bounds__(256) void stm_k_irv_compact(IrvArgs a, uint32_t HW)
+__global__ __launch_bounds__(256) void stm_k_irv_compact(IrvArgs a, uint32_t HW, int zd, int nb)
 {
     const int v = blockIdx.y;
     const u8 *__restrict__ outl = a.outl[v];
+    {   // the same pass packs (outlier flag, disparity) into the 16-bit vote code the vote kernel reads
+        const uint32_t p0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+        for (uint32_t j = 0; j < 4 && p0 + j < HW; ++j) a.code[v][p0 + j] = irv_code(outl[p0 + j], a.disp[v][p0 + j], zd, nb);
+    }
     uint32_t *__restrict__ list = a.list_a[v];
     const uint32_t p = (blockIdx.x * 256u + threadIdx.x) * 4u;
     const int lane = threadIdx.x & 63;
@@ -114,9 +127,9 @@ constexpr int IV_WAVES = 4;     // waves per block
 constexpr int IV_BLOCKS = 1024; // persistent grid per view
 constexpr int IV_U = 4;         // row pairs whose loads are in flight together
 
-// one LDS atomic per voting lane: equal bins serialise inside the LDS atomic unit (<= 64 cycles), which beats a
-// ballot-merge loop whenever a step sees more than a couple of distinct disparities -- and outliers sit exactly
-// where the disparity map is noisy
+// one LDS atomic per voting lane.  Merging equal bins with ballots first was measured slower in both forms tried
+// (unbounded merge loop, and two merge rounds + per-lane fallback): the kernel is instruction-issue bound, not
+// bound by same-address serialisation inside the LDS atomic unit.
 __device__ __forceinline__ void irv_tally(int code, uint32_t *hist, int &total)
 {
     total += __popcll(__ballot(code != -1));
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
     extern __shared__ uint32_t hist_all[]; // [IV_WAVES][nb]
     const int v = blockIdx.y;
     const float *__restrict__ disp = a.disp[v];
-    const u8 *__restrict__ outl = a.outl[v];
+    const int16_t *__restrict__ code_pl = a.code[v];
     const u8 *__restrict__ aL = a.aL[v], *__restrict__ aR = a.aR[v];
     const uint32_t *__restrict__ list = (it & 1) ? a.list_b[v] : a.list_a[v];
     const u8 *__restrict__ dirty = it > 0 ? a.dirty[v] + (size_t)(it - 1) * tiles_x * tiles_y : nullptr;
@@ -185,9 +198,7 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
             }
             const int jend = min(nrows - jb, 128);
             for (int j0 = 0; j0 < jend; j0 += IV_U) {
-                u8 o[IV_U];
-                float dv[IV_U];
-                int wd[IV_U], base[IV_U];
+                int cd[IV_U], wd[IV_U], base[IV_U];
                 int wmax = 0;
 #pragma unroll
                 for (int u = 0; u < IV_U; ++u) { // first 64 pixels of IV_U rows: all loads issued before any is consumed
@@ -201,31 +212,17 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
                     wd[u] = w;
                     wmax = max(wmax, w);
                     base[u] = (y_top + jb + j) * W + xs;
-                    o[u] = 1;
-                    dv[u] = 0.f;
-                    if (lane < w) {
-                        o[u] = outl[base[u] + lane];
-                        dv[u] = disp[base[u] + lane];
-                    }
+                    cd[u] = -1; // -1: no vote (outside the row segment, or an outlier itself)
+                    if (lane < w) cd[u] = code_pl[base[u] + lane];
                 }
 #pragma unroll
-                for (int u = 0; u < IV_U; ++u) {
-                    int code = -1; // -1: no vote (outside the row segment, or an outlier itself)
-                    if (o[u] == 0) {
-                        const int b = (int)dv[u] + zd;      // d_dr_irv.cu:200-201
-                        code = (b >= 0 && b < nb) ? b : -2; // -2: reliable, but its bin is out of range
-                    }
-                    irv_tally(code, hist, total);
-                }
+                for (int u = 0; u < IV_U; ++u) irv_tally(cd[u], hist, total);
                 if (wmax > 64) { // segments wider than 64 pixels (arm sum >= 64): rare
 #pragma unroll
                     for (int u = 0; u < IV_U; ++u) {
                         for (int c0 = 64; c0 < wd[u]; c0 += 64) {
                             int code = -1;
-                            if (c0 + lane < wd[u] && outl[base[u] + c0 + lane] == 0) {
-                                const int b = (int)disp[base[u] + c0 + lane] + zd;
-                                code = (b >= 0 && b < nb) ? b : -2;
-                            }
+                            if (c0 + lane < wd[u]) code = code_pl[base[u] + c0 + lane];
                             irv_tally(code, hist, total);
                         }
                     }
@@ -258,7 +255,7 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
 
 // dr_irv_kernel_3 (d_dr_irv.cu:17-43) over the outlier list only (it touches nothing else), fused with the
 // construction of the next iteration's list: pixels that stay outliers are appended to the other list.
-__global__ __launch_bounds__(256) void stm_k_irv_apply(IrvArgs a, int it, int thresh_s, float thresh_h, int zd, int W,
+__global__ __launch_bounds__(256) void stm_k_irv_apply(IrvArgs a, int it, int thresh_s, float thresh_h, int zd, int nb, int W,
                                                        int tiles_x, int tiles_y)
 {
     const int v = blockIdx.y;
@@ -273,6 +270,7 @@ __global__ __launch_bounds__(256) void stm_k_irv_apply(IrvArgs a, int it, int th
             a.outl[v][p] = 0;
             a.reliable[v][p] = tr + 1;
             a.disp[v][p] = (float)md;
+            a.code[v][p] = irv_code(0, (float)md, zd, nb);
             const int gy = (int)(p / (uint32_t)W), gx = (int)(p - (uint32_t)gy * (uint32_t)W);
             a.dirty[v][(size_t)it * tiles_x * tiles_y + (gy / IV_TILE) * tiles_x + gx / IV_TILE] = 1; // same value from every writer
         } else {
@@ -306,19 +304,20 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
         a.reliable[v] = Workspace::get<int>(HW);
         a.list_a[v] = Workspace::get<uint32_t>(HW);
         a.list_b[v] = Workspace::get<uint32_t>(HW);
+        a.code[v] = Workspace::get<int16_t>(HW);
     }
-    if (nviews == 1) { a.max_disp[1] = a.max_disp[0]; a.reliable[1] = a.reliable[0]; a.list_a[1] = a.list_a[0]; a.list_b[1] = a.list_b[0]; }
+    if (nviews == 1) { a.max_disp[1] = a.max_disp[0]; a.reliable[1] = a.reliable[0]; a.list_a[1] = a.list_a[0]; a.list_b[1] = a.list_b[0]; a.code[1] = a.code[0]; }
     if (rounds == 0) return; // nothing observable happens (a host-flavour vote without an apply only fills scratch)
     ProfScope p("irv");
     STM_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * 2 * (size_t)(rounds + 2) + 2 * dirty_sz, stream()));
-    hipLaunchKernelGGL(stm_k_irv_compact, dim3((unsigned)((HW + 1023) / 1024), nviews), dim3(256), 0, stream(), a, (uint32_t)HW);
+    hipLaunchKernelGGL(stm_k_irv_compact, dim3((unsigned)((HW + 1023) / 1024), nviews), dim3(256), 0, stream(), a, (uint32_t)HW, zd, nb);
     STM_CHECK_LAUNCH();
     const size_t smem = (size_t)nb * IV_WAVES * 4;
     for (int it = 0; it < rounds; ++it) {
         hipLaunchKernelGGL(stm_k_irv_vote, dim3(IV_BLOCKS, nviews), dim3(64 * IV_WAVES), smem, stream(), a, it, H, W, nb, zd, usd,
                            tiles_x, tiles_y);
         STM_CHECK_LAUNCH();
-        hipLaunchKernelGGL(stm_k_irv_apply, dim3(256, nviews), dim3(256), 0, stream(), a, it, thresh_s, thresh_h, zd, W, tiles_x,
+        hipLaunchKernelGGL(stm_k_irv_apply, dim3(256, nviews), dim3(256), 0, stream(), a, it, thresh_s, thresh_h, zd, nb, W, tiles_x,
                            tiles_y);
         STM_CHECK_LAUNCH();
     }
