@@ -21,6 +21,9 @@
  *   cross arms  table of 4 pointers to u8 planes, order UP, DOWN, LEFT, RIGHT
  *   disparity   float [H][W], signed offset (d - zero_disp)
  *
+ * Threading: like the reference (single host thread, default stream) the library keeps one cached
+ * workspace per device and one current stream per thread; calls that share a device must not overlap in time.
+ *
  * Errors: like the reference (cuda_utils.h:12-21) a HIP failure prints a message and
  * calls exit(1); unlike it, kernel launches are checked too.  stm_set_error_mode(1)
  * turns that into "record and return" for embedding hosts (query stm_last_error()).
