@@ -494,3 +494,38 @@ def test_device_frame_pipeline_with_hslo(gpu_ready, orc, stages):
     assert np.array_equal(dl.cpu().numpy(), want[key + "_l"]) and np.array_equal(dr.cpu().numpy(), want[key + "_r"])
     if stages == 3:
         assert np.array_equal(out.cpu().numpy(), want["interlaced"])
+
+
+def test_image_cli_matches_stage_chain(gpu_ready, orc, golden, tmp_path):
+    """tools/stm_image.py = image_io.cpp without the window: its interlaced BMP equals the oracle's stage chain with the
+    still-image driver's constants (IRV x1 host flavour, bilateral 7/7/7, dibr_dbm gaussian 7/10)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from stm_amd import bmp_io
+    L, R = golden["L"], golden["R"]
+    H, W, _ = L.shape
+    bmp_io.write_bmp(str(tmp_path / "l.bmp"), L)
+    bmp_io.write_bmp(str(tmp_path / "r.bmp"), R)
+    D, zd, usd, lsd, N = 8, 5, 9, 4, 8
+    out = tmp_path / "o"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "stm_image.py"), str(tmp_path / "l.bmp"), str(tmp_path / "r.bmp"),
+                           "10", "30", str(D), str(zd), "6", "20", str(usd), str(lsd), str(N), "18.43", str(W), str(H), "20", "0.4", str(out)])
+    cl, cr = orc.ci_adcensus(L, R, 10.0, 30.0, D, zd)
+    xl, al = orc.ca_cross(L, cl, 6.0, 20.0, usd, lsd)
+    xr, ar = orc.ca_cross(R, cr, 6.0, 20.0, usd, lsd)
+    dl, dr = orc.dc_wta(al, zd), orc.dc_wta(ar, zd)
+    ol, orr = orc.dr_dcc(dl, dr)
+    dl, ol = orc.dr_irv(dl, ol, xl, 20, 0.4, D, zd, usd, 1, device_flavour=False)
+    dr, orr = orc.dr_irv(dr, orr, xr, 20, 0.4, D, zd, usd, 1, device_flavour=False)
+    dl, dr = orc.filter_bilateral_1(dl, 7, 7.0, 7.0, D), orc.filter_bilateral_1(dr, 7, 7.0, 7.0, D)
+    occl_l, occl_r = orc.dibr_occl(dl, dr)
+    ml, mr = orc.dibr_occl_to_mask(orc.filter_bleed_1(occl_l, 1), orc.filter_bleed_1(occl_r, 1))
+    views = [R]
+    for v in range(1, N - 1):
+        shift = float(np.float32(1.0 - (1.0 * np.float32(v)) / (np.float32(N) - 1.0)))
+        views.append(orc.dibr_dbm(L, R, dl, dr, ml, mr, shift, 7, 10.0))
+    views.append(L)
+    want = orc.mux_multiview(views, 18.43, H, W, 2)
+    assert np.array_equal(bmp_io.read_bmp(str(out / "interlaced.bmp")), want)
+    assert np.array_equal(bmp_io.read_bmp(str(out / "view_3.bmp")), views[3])
