@@ -25,8 +25,11 @@ def orc():
 
 @pytest.fixture(scope="session")
 def stm():
-    """The product package (host mirror of the C ABI)."""
+    """The product package (host mirror of the C ABI).  If the HIP library has not been built in this tree yet it is
+    BUILT (hipcc, gfx950) -- never substituted: there is no other implementation to fall back to."""
     import stm_amd
+    if not os.path.exists(stm_amd.LIB_PATH):
+        stm_amd.build()
     return stm_amd
 
 
