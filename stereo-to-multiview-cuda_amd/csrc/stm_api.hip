@@ -244,7 +244,7 @@ void stm_d_dc_hslo(float **d_cost, float *d_disp, unsigned char *d_img_l, unsign
                    float H2, int num_disp, int zero_disp, int num_rows, int num_cols, int elem_sz)
 {
     size_t HW = (size_t)num_rows * num_cols;
-    Workspace::begin((size_t)num_disp * HW * 16 + 8 * HW + 8192);
+    Workspace::begin((size_t)((num_disp + 3) / 4) * HW * 16 * 6 + 16 * HW + 16384);
     Vol c = vol_table(d_cost);
     const u8 *ia[1] = {d_img_l}, *ib[1] = {d_img_r};
     const int os[1] = {1};
@@ -255,7 +255,7 @@ void stm_dc_hslo(float **cost, float *disp, unsigned char *img_l, unsigned char 
                  int num_disp, int zero_disp, int num_rows, int num_cols, int elem_sz)
 {
     size_t HW = (size_t)num_rows * num_cols, V = HW * num_disp;
-    Workspace::begin(5 * V * 4 + 2 * HW * elem_sz + 3 * HW * 4 + 16384);
+    Workspace::begin(V * 4 + (size_t)((num_disp + 3) / 4) * HW * 16 * 6 + 2 * HW * elem_sz + 5 * HW * 4 + 32768);
     float *c = up_planes(cost, num_disp, HW);
     u8 *dl = up(img_l, HW * elem_sz), *dr = up(img_r, HW * elem_sz);
     float *d = Workspace::get<float>(HW);
@@ -581,7 +581,7 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
     const int H = num_rows, W = num_cols, N = num_views;
     const size_t HW = (size_t)H * W, IMG = HW * elem_sz;
     const size_t V = HW * (size_t)((num_disp + 3) / 4) * 4;
-    Workspace::begin(((stages & 0x100) ? 11 : 3) * V * 4 + (size_t)(N + 2) * IMG + 112 * HW + (1u << 20));
+    Workspace::begin(((stages & 0x100) ? 13 : 3) * V * 4 + (size_t)(N + 2) * IMG + 112 * HW + (1u << 20));
     u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
     launch_demux_sbs(img_l, img_r, d_img_sbs, H, num_cols_sbs, W, elem_sz);
     Arms al, ar;

@@ -4,147 +4,183 @@
 // :97-221 driver that never writes `disp`, call site commented out at image_io.cpp:310-316), so
 // parity is UNPINNED: the algorithm is Mei et al. section 3.3 with the penalty rule the reference
 // does express (dc_hslo_h_cdiff_kernel, d_dc_hslo.cu:73-93; constants :124-127).  The definition the
-// oracle and this file share is written out in oracle/stm_oracle.c (orc_dc_hslo_slab).
+// oracle and this file share is written out in oracle/stm_oracle.c (orc_dc_hslo_slab2).
 //
-// Mapping: the recurrence is sequential along a scan line and parallel over lines and hypotheses, so
-// ONE WAVE OWNS ONE LINE and its lanes are the hypotheses d (D <= 64 * DPL, DPL values per lane).
-// Per pixel of the line: the neighbours Cr(p-r, d+-1) come from DPP wave shifts (no LDS), the minimum
-// over d of the new path costs is a 6-step DPP reduction, the right-image colour step D2 is a
-// coalesced load (lane d looks at column x + d - zd).  Cost / accumulator accesses touch 64 planes
-// at one pixel (one 4-byte element per plane); horizontal lines re-use those cache lines for the next
-// 31 pixels, vertical lines share them with the neighbouring columns' waves of the same block.
+// Mapping.  The recurrence is sequential along a scan line and parallel over lines x hypotheses, so ONE WAVE
+// OWNS ONE LINE and, while it walks the line, its lanes are the hypotheses d (D <= 64 * DPL): Cr(p-r, d+-1) come
+// from DPP wave shifts, min_k Cr(p-r, k) from a 6-step DPP reduction -- no LDS, no barrier on the critical path.
+// Memory, however, wants lanes along the line.  So a line is processed in chunks of 32 pixels through an LDS tile
+// [pixel][d] that the wave fills with coalesced 16-byte quads (lane = pixel), walks (lane = d, in place) and writes
+// back coalesced: a transposition through LDS private to the wave (no block barriers).
+// Vertical lines are made horizontal first: the cost volume is transposed once per call (quads [q][W][H]), the
+// top->bottom / bottom->top passes run on the transposed volume, and the combine kernel reads their results back
+// through an LDS tile transposition.  All line passes (2 directions x views, per orientation) share a launch.
 #include "stm_common.h"
+#include <cstdlib>
 
 namespace stm {
 
-// colour averages used by the penalty rule: left = integer mean as u8 (d_dc_hslo.cu:57-58), right = float mean (:66-67)
-__global__ __launch_bounds__(256) void stm_k_hslo_avg(const u8 *__restrict__ img_l, const u8 *__restrict__ img_r,
-                                                      float *__restrict__ avg_l, float *__restrict__ avg_r, size_t HW, int elem_sz)
+// ------------------------------------------------------------------ small helpers
+// colour averages used by the penalty rule, in both orientations:
+// own image = integer mean as u8 (d_dc_hslo.cu:57-58), other image = float mean (:66-67)
+__global__ __launch_bounds__(256) void stm_k_hslo_avg(const u8 *__restrict__ img_a, const u8 *__restrict__ img_b,
+                                                      float *__restrict__ avg_a, float *__restrict__ avg_b,
+                                                      float *__restrict__ avg_at, float *__restrict__ avg_bt, int H, int W,
+                                                      int elem_sz)
 {
-    size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const size_t p = (size_t)y * W + x, pt = (size_t)x * H + y;
+    const u8 *l = img_a + p * elem_sz, *r = img_b + p * elem_sz;
+    const float va = (float)(u8)(((int)l[0] + (int)l[1] + (int)l[2]) / 3);
+    const float vb = (float)((double)(float)((int)r[0] + (int)r[1] + (int)r[2]) / 3.0);
+    avg_a[p] = va; avg_b[p] = vb;
+    avg_at[pt] = va; avg_bt[pt] = vb;
+}
+
+// any layout -> quads float4 [NQ][H][W] (only needed when the caller's volume is a plane table / slab)
+__global__ __launch_bounds__(256) void stm_k_to_quads(Vol in, float4 *__restrict__ out, int D, size_t HW)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int q = blockIdx.y;
     if (p >= HW) return;
-    const u8 *l = img_l + p * elem_sz, *r = img_r + p * elem_sz;
-    avg_l[p] = (float)(u8)(((int)l[0] + (int)l[1] + (int)l[2]) / 3);
-    avg_r[p] = (float)((double)(float)((int)r[0] + (int)r[1] + (int)r[2]) / 3.0);
+    out[(size_t)q * HW + p] = load_quad<false>(in, q, D, p);
+}
+
+// quads [q][A][B] -> quads [q][B][A], 32x32 tiles of float4 through LDS
+__global__ __launch_bounds__(256) void stm_k_transpose_quads(const float4 *__restrict__ in, float4 *__restrict__ out, int A, int B)
+{
+    __shared__ float4 tile[32][33];
+    const int q = blockIdx.z, b0 = blockIdx.x * 32, a0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    const float4 *src = in + (size_t)q * A * B;
+    float4 *dst = out + (size_t)q * A * B;
+    for (int r = ty; r < 32; r += 8)
+        if (a0 + r < A && b0 + tx < B) tile[r][tx] = src[(size_t)(a0 + r) * B + b0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (b0 + r < B && a0 + tx < A) dst[(size_t)(b0 + r) * A + a0 + tx] = tile[tx][r];
 }
 
 #define STM_DPP(old, v, ctrl) \
     __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(v)), ctrl, 0xf, 0xf, false))
 
-// min over the 64 lanes (min is idempotent, so the row masks of the classic reduction are not needed);
-// lanes a source does not reach keep +inf.  The result is broadcast from lane 63.
+// min over the 64 lanes, result broadcast from lane 63.  Six v_min_f32 with a DPP source operand: a lane whose
+// DPP source does not exist is simply not written (bound_ctrl off), and min is idempotent, so the row masks of the
+// classic reduction are not needed.  Written as inline asm because clang expands fminf(x, dpp(x)) into
+// mov-immediate + v_mov_dpp + a canonicalising v_max + v_min (4 instructions per step on the critical path of every
+// pixel of every line); the s_nop covers the VALU-write -> DPP-read hazard the assembler does not pad for us.
 __device__ __forceinline__ float wave_min(float v)
 {
-    const float inf = __builtin_inff();
-    v = fminf(v, STM_DPP(inf, v, 0x111)); // row_shr:1
-    v = fminf(v, STM_DPP(inf, v, 0x112)); // row_shr:2
-    v = fminf(v, STM_DPP(inf, v, 0x114)); // row_shr:4
-    v = fminf(v, STM_DPP(inf, v, 0x118)); // row_shr:8   -> lane 15 of every row holds the row minimum
-    v = fminf(v, STM_DPP(inf, v, 0x142)); // row_bcast:15 -> lanes 31 and 63 hold the minimum of two rows
-    v = fminf(v, STM_DPP(inf, v, 0x143)); // row_bcast:31 -> lane 63 holds the wave minimum
+    asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-template <bool QUAD> __device__ __forceinline__ float *elem_ptr(const Vol &v, int d, size_t p)
+__device__ __forceinline__ void wave_lds_fence()
 {
-    if (QUAD) return v.base + ((size_t)(d >> 2) * v.plane_stride + p) * 4 + (d & 3);
-    return v.plane(d) + p;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
-struct HsloArgs {
-    Vol cost[2];          // per view
-    float *out[2];        // per view: 4 direction volumes as quads, float4 [4][ceil(D/4)][H*W]
-    const float *avg_a[2]; // per view: integer-mean plane of the view's own image ("left" role, d_dc_hslo.cu:57-58)
-    const float *avg_b[2]; // per view: float-mean plane of the other image ("right" role, :66-67)
+// ------------------------------------------------------------------ line passes
+struct HsloLineArgs {
+    const float4 *cost[2]; // per view: quads [NQ][nlines][len] in the orientation of this launch
+    float4 *out[2];        // per view: two direction volumes, quads [2][NQ][nlines][len]
+    const float *avg_a[2]; // per view: own-image averages, [nlines][len]
+    const float *avg_b[2]; // per view: other-image averages, [nlines][len]
     int osign[2];          // +1 left view (matched pixel x + d - zd), -1 right view (x - (d - zd))
 };
 
-// Everything a step needs that does NOT depend on the recurrence (cost, the colour averages behind the penalty
-// class) is fetched a whole CHUNK of K steps ahead, so only the DPP chain (min over d, neighbours, compares) is on
-// the critical path of a line.
-template <int DPL> struct HsloRaw {
-    float c[DPL], r0[DPL], r1[DPL];
-    float l0, l1;
-    size_t p;
-};
 
-// grid = (lines / 4, 4 directions, views): the four directions and both views are independent, so they run in
-// ONE launch (8x the waves of a single direction: a line is a long dependent chain and only ~1-2K lines exist).
-// Every direction writes its own volume; the fixed-order sum ((lr + rl) + tb) + bt happens in the combine kernel.
-// dir: 0 = left->right, 1 = right->left, 2 = top->bottom, 3 = bottom->top
-template <int DPL, int K, bool QUAD>
-__global__ __launch_bounds__(256) void stm_k_hslo_dir(HsloArgs a, float T, float P1a, float P1b, float P1c, float P2a,
-                                                      float P2b, float P2c, int D, int zd, int H, int W)
+// grid = (lines / WPB, 2 directions, views); block = WPB waves, one line each.
+// PERP = false: the line runs along x (matched pixels slide along the line);
+// PERP = true : the volume is transposed, the line runs along y and the matched pixel of hypothesis d sits in line
+//               `line + osign (d - zd)` at the same position.
+// CW = pixels per chunk (8, 16 or 32): the smaller the tile, the more lines are resident per CU.
+template <int DPL, int WPB, bool PERP, int CW>
+__global__ __launch_bounds__(64 * WPB) void stm_k_hslo_lines(HsloLineArgs a, float T, float P1a, float P1b, float P1c, float P2a,
+                                                             float P2b, float P2c, int D, int zd, int nlines, int len)
 {
-    const int dir = blockIdx.y, view = blockIdx.z;
-    const Vol cost = a.cost[view];
-    const size_t HW = (size_t)H * W;
+    constexpr int DP = 64 * DPL + 4; // tile row pitch in floats: conflict-free for b128 rows and for lane = d columns
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int line = blockIdx.x * WPB + wave;
+    if (line >= nlines) return; // whole wave; there are no block barriers in this kernel
+    const int bwd = blockIdx.y, view = blockIdx.z;
     const int NQ = (D + 3) >> 2;
-    float *__restrict__ out = a.out[view] + (size_t)dir * NQ * HW * 4; // element (d, p) at ((d >> 2) * HW + p) * 4 + (d & 3)
-    const float *__restrict__ avg_l = a.avg_a[view], *__restrict__ avg_r = a.avg_b[view];
+    const int PAD = max(max(zd, D - 1 - zd), 0);
+    const int seg_len = ((PERP ? D * (CW + 1) : CW + 2 * PAD) + 3) & ~3; // keep every wave's tile 16-byte aligned
+    float *tile = lds + (size_t)wave * (CW * DP + seg_len);
+    float *seg = tile + CW * DP;
+    const float4 *__restrict__ cost = a.cost[view];
+    float4 *__restrict__ out = a.out[view] + (size_t)bwd * NQ * nlines * len;
+    const float *__restrict__ avg_a = a.avg_a[view], *__restrict__ avg_b = a.avg_b[view];
     const int osign = a.osign[view];
-    const int lane = threadIdx.x & 63;
-    const int line = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const bool horiz = dir < 2;
-    const int nlines = horiz ? H : W, len = horiz ? W : H;
-    if (line >= nlines) return; // whole wave
-    const int dx = dir == 0 ? 1 : (dir == 1 ? -1 : 0), dy = dir == 2 ? 1 : (dir == 3 ? -1 : 0);
+    constexpr int G = 64 / CW; // pixel groups per wave instruction in the fill and drain
+    const int px = lane & (CW - 1), h = lane / CW;
     const float inf = __builtin_inff();
 
-    auto fetch = [&](int i, HsloRaw<DPL> &in) {
-        const int ii = min(i, len - 1); // steps past the end are fetched (in range) and never used
-        const int x = horiz ? (dx > 0 ? ii : W - 1 - ii) : line;
-        const int y = horiz ? line : (dy > 0 ? ii : H - 1 - ii);
-        in.p = (size_t)y * W + x;
-        const int px = ii > 0 ? x - dx : x, py = ii > 0 ? y - dy : y; // previous pixel of the line
-        in.l0 = avg_l[in.p];
-        in.l1 = avg_l[(size_t)py * W + px];
+    float prev[DPL], rprev[DPL];
 #pragma unroll
-        for (int j = 0; j < DPL; ++j) {
-            const int d = min(lane + 64 * j, D - 1);
-            in.c[j] = *elem_ptr<QUAD>(cost, d, in.p);
-            const int o = osign * (d - zd);
-            const int qx = min(max(x + o, 0), W - 1), qpx = min(max(px + o, 0), W - 1);
-            in.r0[j] = avg_r[(size_t)y * W + qx];
-            in.r1[j] = avg_r[(size_t)py * W + qpx];
+    for (int j = 0; j < DPL; ++j) { prev[j] = inf; rprev[j] = 0.f; }
+    float lprev = 0.f;
+    bool started = false;
+    const int nchunks = (len + CW - 1) / CW;
+    for (int c = 0; c < nchunks; ++c) {
+        const int lo = bwd ? max(len - CW * (c + 1), 0) : c * CW;
+        const int hi = bwd ? len - CW * c : min(lo + CW, len);
+        const int n = hi - lo;
+        // ---- fill: lane = pixel, 16-byte quads, two quads per wave instruction
+        wave_lds_fence();
+        if (px < n) {
+            for (int q = h; q < NQ; q += G)
+                *(float4 *)(tile + px * DP + 4 * q) = cost[((size_t)q * nlines + line) * len + lo + px];
         }
-    };
-
-    float prev[DPL];
-#pragma unroll
-    for (int j = 0; j < DPL; ++j) prev[j] = inf;
-    HsloRaw<DPL> nxt[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) fetch(k, nxt[k]);
-    for (int i0 = 0; i0 < len; i0 += K) {
-        HsloRaw<DPL> cur_in[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) cur_in[k] = nxt[k];
-        if (i0 + K < len) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) fetch(i0 + K + k, nxt[k]);
+        if (PERP) { // seg[d][t] = other-image average of line `line + osign (d - zd)` at position lo + t
+            for (int d = h; d < D; d += G) {
+                const int ln = min(max(line + osign * (d - zd), 0), nlines - 1);
+                if (px < n) seg[d * (CW + 1) + px] = avg_b[(size_t)ln * len + lo + px];
+            }
+        } else { // seg[i] = other-image average of this line at position clamp(lo - PAD + i)
+            for (int i = lane; i < n + 2 * PAD; i += 64)
+                seg[i] = avg_b[(size_t)line * len + min(max(lo - PAD + i, 0), len - 1)];
         }
+        // own-image averages of the chunk: lane t holds position lo + t, broadcast per step with v_readlane
+        const float lrow = lane < n ? avg_a[(size_t)line * len + lo + lane] : 0.f;
+        wave_lds_fence();
+        // ---- walk: lane = hypothesis, tile updated in place
+        for (int k = 0; k < n; ++k) {
+            const int t = bwd ? n - 1 - k : k;
+            const float l0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lrow), t));
+            float cc[DPL], r0[DPL];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int i = i0 + k;
-            if (i >= len) break; // wave-uniform
-            const HsloRaw<DPL> &in = cur_in[k];
-            if (i == 0) {
+            for (int j = 0; j < DPL; ++j) {
+                const int d = min(lane + 64 * j, D - 1);
+                cc[j] = tile[t * DP + d];
+                r0[j] = PERP ? seg[d * (CW + 1) + t] : seg[t + PAD + osign * (d - zd)];
+            }
+            if (!started) { // first pixel of the line: Cr(p0, d) = C(p0, d)
 #pragma unroll
                 for (int j = 0; j < DPL; ++j) {
-                    const int d = lane + 64 * j;
-                    if (d < D) {
-                        prev[j] = in.c[j];
-                        out[((size_t)(d >> 2) * HW + in.p) * 4 + (d & 3)] = in.c[j];
-                    }
+                    prev[j] = lane + 64 * j < D ? cc[j] : inf;
+                    rprev[j] = r0[j];
                 }
+                lprev = l0;
+                started = true;
                 continue;
             }
             float mloc = prev[0];
 #pragma unroll
             for (int j = 1; j < DPL; ++j) mloc = fminf(mloc, prev[j]);
-            const float m = wave_min(mloc); // min_k Cr(p-r, k); inactive lanes hold +inf
-            const float D1 = fabsf(in.l0 - in.l1);
+            const float m = wave_min(mloc); // min_k Cr(p-r, k); absent hypotheses hold +inf
+            const float D1 = fabsf(l0 - lprev);
             float cur[DPL];
 #pragma unroll
             for (int j = 0; j < DPL; ++j) {
@@ -162,79 +198,138 @@ __global__ __launch_bounds__(256) void stm_k_hslo_dir(HsloArgs a, float T, float
                 }
                 cur[j] = inf;
                 if (d < D) {
-                    const float D2 = fabsf(in.r0[j] - in.r1[j]);
+                    const float D2 = fabsf(r0[j] - rprev[j]);
                     float P1, P2;
                     if (D1 < T && D2 < T) { P1 = P1a; P2 = P2a; }
                     else if ((D1 < T && D2 > T) || (D1 > T && D2 < T)) { P1 = P1b; P2 = P2b; }
                     else { P1 = P1c; P2 = P2c; }
                     float best = prev[j];
-                    if (d > 0) { const float t = below + P1; if (t < best) best = t; }
-                    if (d < D - 1) { const float t = above + P1; if (t < best) best = t; }
-                    { const float t = m + P2; if (t < best) best = t; }
-                    float v = in.c[j] + best;
+                    if (d > 0) { const float tt = below + P1; if (tt < best) best = tt; }
+                    if (d < D - 1) { const float tt = above + P1; if (tt < best) best = tt; }
+                    { const float tt = m + P2; if (tt < best) best = tt; }
+                    float v = cc[j] + best;
                     v = v - m;
                     cur[j] = v;
-                    out[((size_t)(d >> 2) * HW + in.p) * 4 + (d & 3)] = v;
+                    tile[t * DP + d] = v;
                 }
             }
 #pragma unroll
-            for (int j = 0; j < DPL; ++j) prev[j] = cur[j];
+            for (int j = 0; j < DPL; ++j) { prev[j] = cur[j]; rprev[j] = r0[j]; }
+            lprev = l0;
+        }
+        // ---- drain: lane = pixel again
+        wave_lds_fence();
+        if (px < n) {
+            for (int q = h; q < NQ; q += G)
+                out[((size_t)q * nlines + line) * len + lo + px] = *(const float4 *)(tile + px * DP + 4 * q);
         }
     }
 }
 
-// C2(p, d) = (((C_lr + C_rl) + C_tb) + C_bt) * 0.25f, then first-lowest-wins WTA (d_dc_wta.cu:19-34); optionally the
-// combined volume is written (dense [D][H*W]) for callers that want it
-__global__ __launch_bounds__(256) void stm_k_hslo_combine_wta(HsloArgs a, float *disp0, float *disp1, float *vol0, float *vol1,
-                                                              int D, int zd, size_t HW)
+// ------------------------------------------------------------------ combine + WTA
+// C2(p, d) = (((C_lr + C_rl) + C_tb) + C_bt) * 0.25f, then first-lowest-wins WTA (d_dc_wta.cu:19-34).  The two
+// vertical results live in the transposed orientation and come back through a 32x32 LDS tile per quad.
+struct HsloCombineArgs {
+    const float4 *out_h[2], *out_v[2]; // per view: [2][NQ][H][W] and [2][NQ][W][H]
+    float *disp[2];
+    float *vol[2]; // optional dense [D][H*W] copy of the combined volume
+};
+
+__global__ __launch_bounds__(256) void stm_k_hslo_combine_wta(HsloCombineArgs a, int D, int zd, int H, int W)
 {
-    const int view = blockIdx.y;
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
-    const float4 *__restrict__ o = (const float4 *)a.out[view];
-    float *__restrict__ disp = view ? disp1 : disp0;
-    float *__restrict__ vol = view ? vol1 : vol0;
+    __shared__ float4 t2[32][33], t3[32][33];
+    const int view = blockIdx.z;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8, each thread owns pixels (x0+tx, y0+ty+8i)
     const int NQ = (D + 3) >> 2;
-    const size_t V4 = (size_t)NQ * HW;
-    float lowest = 3.402823466e+38f;
-    int best = 0;
-    for (int q = 0; q < NQ; ++q) {
-        const size_t i = (size_t)q * HW + p;
-        const float4 a0 = o[i], a1 = o[V4 + i], a2 = o[2 * V4 + i], a3 = o[3 * V4 + i];
-        float s[4];
-        s[0] = a0.x + a1.x; s[0] = s[0] + a2.x; s[0] = s[0] + a3.x; s[0] = s[0] * 0.25f;
-        s[1] = a0.y + a1.y; s[1] = s[1] + a2.y; s[1] = s[1] + a3.y; s[1] = s[1] * 0.25f;
-        s[2] = a0.z + a1.z; s[2] = s[2] + a2.z; s[2] = s[2] + a3.z; s[2] = s[2] * 0.25f;
-        s[3] = a0.w + a1.w; s[3] = s[3] + a2.w; s[3] = s[3] + a3.w; s[3] = s[3] * 0.25f;
+    const size_t HW = (size_t)H * W, VQ = (size_t)NQ * HW;
+    const float4 *__restrict__ oh = a.out_h[view], *__restrict__ ov = a.out_v[view];
+    float lowest[4];
+    int best[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int d = 4 * q + e;
-            if (d < D) {
-                if (vol) vol[(size_t)d * HW + p] = s[e];
-                if (lowest > s[e]) { lowest = s[e]; best = d; }
+    for (int i = 0; i < 4; ++i) { lowest[i] = 3.402823466e+38f; best[i] = 0; }
+    for (int q = 0; q < NQ; ++q) {
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) { // transposed volumes: row = x, contiguous along y
+            const int x = x0 + r, y = y0 + tx;
+            if (x < W && y < H) {
+                t2[r][tx] = ov[((size_t)q * W + x) * H + y];
+                t3[r][tx] = ov[VQ + ((size_t)q * W + x) * H + y];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x = x0 + tx, y = y0 + ty + 8 * i;
+            if (x < W && y < H) {
+                const size_t p = (size_t)y * W + x;
+                const float4 a0 = oh[(size_t)q * HW + p], a1 = oh[VQ + (size_t)q * HW + p];
+                const float4 a2 = t2[tx][ty + 8 * i], a3 = t3[tx][ty + 8 * i];
+                float s[4];
+                s[0] = a0.x + a1.x; s[0] = s[0] + a2.x; s[0] = s[0] + a3.x; s[0] = s[0] * 0.25f;
+                s[1] = a0.y + a1.y; s[1] = s[1] + a2.y; s[1] = s[1] + a3.y; s[1] = s[1] * 0.25f;
+                s[2] = a0.z + a1.z; s[2] = s[2] + a2.z; s[2] = s[2] + a3.z; s[2] = s[2] * 0.25f;
+                s[3] = a0.w + a1.w; s[3] = s[3] + a2.w; s[3] = s[3] + a3.w; s[3] = s[3] * 0.25f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int d = 4 * q + e;
+                    if (d < D) {
+                        if (a.vol[view]) a.vol[view][(size_t)d * HW + p] = s[e];
+                        if (lowest[i] > s[e]) { lowest[i] = s[e]; best[i] = d; }
+                    }
+                }
             }
         }
     }
-    disp[p] = (float)best - (float)zd;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = x0 + tx, y = y0 + ty + 8 * i;
+        if (x < W && y < H) a.disp[view][(size_t)y * W + x] = (float)best[i] - (float)zd;
+    }
 }
 
-template <int DPL>
-static void hslo_launch(const HsloArgs &a, int nviews, float T, const float *P1, const float *P2, int D, int zd, int H, int W)
+// ------------------------------------------------------------------ driver
+#ifndef HSLO_CW_H
+#define HSLO_CW_H 16
+#endif
+#ifndef HSLO_CW_V
+#define HSLO_CW_V 8
+#endif
+template <int DPL, int WPB, bool PERP, int CW>
+static void hslo_lines_launch(const HsloLineArgs &a, int nviews, float T, const float *P1, const float *P2, int D, int zd, int nlines,
+                              int len)
 {
-    constexpr int K = DPL == 1 ? 8 : (DPL == 2 ? 4 : 2);
-    const int nl = H > W ? H : W;
-    if (a.cost[0].quad)
-        hipLaunchKernelGGL((stm_k_hslo_dir<DPL, K, true>), dim3(cdiv(nl, 4), 4, nviews), dim3(256), 0, stream(), a, T, P1[0], P1[1],
-                           P1[2], P2[0], P2[1], P2[2], D, zd, H, W);
-    else
-        hipLaunchKernelGGL((stm_k_hslo_dir<DPL, K, false>), dim3(cdiv(nl, 4), 4, nviews), dim3(256), 0, stream(), a, T, P1[0], P1[1],
-                           P1[2], P2[0], P2[1], P2[2], D, zd, H, W);
+    const int PAD = D - 1 - zd > zd ? D - 1 - zd : (zd > 0 ? zd : 0);
+    const size_t per_wave = (size_t)CW * (64 * DPL + 4) + (((PERP ? (size_t)D * (CW + 1) : (size_t)CW + 2 * PAD) + 3) & ~(size_t)3);
+    const size_t smem = per_wave * WPB * 4;
+    if (smem > 64 * 1024)
+        STM_CHECK(hipFuncSetAttribute((const void *)stm_k_hslo_lines<DPL, WPB, PERP, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((stm_k_hslo_lines<DPL, WPB, PERP, CW>), dim3(cdiv(nlines, WPB), 2, nviews), dim3(64 * WPB), smem, stream(), a, T, P1[0],
+                       P1[1], P1[2], P2[0], P2[1], P2[2], D, zd, nlines, len);
     STM_CHECK_LAUNCH();
 }
 
-// Scanline optimisation + WTA for 1 or 2 views in three launches (colour averages, 4 directions x views, combine).
+template <bool PERP, int CW>
+static void hslo_lines_cw(const HsloLineArgs &a, int nviews, float T, const float *P1, const float *P2, int D, int zd, int nlines, int len)
+{
+    if (D <= 64) hslo_lines_launch<1, 4, PERP, CW>(a, nviews, T, P1, P2, D, zd, nlines, len);
+    else if (D <= 128) hslo_lines_launch<2, 2, PERP, CW>(a, nviews, T, P1, P2, D, zd, nlines, len);
+    else hslo_lines_launch<4, 1, PERP, CW>(a, nviews, T, P1, P2, D, zd, nlines, len);
+}
+template <bool PERP>
+static void hslo_lines(const HsloLineArgs &a, int nviews, float T, const float *P1, const float *P2, int D, int zd, int nlines, int len)
+{
+    static const int cw_env = [] { const char *e = getenv(PERP ? "STM_HSLO_CW_V" : "STM_HSLO_CW_H"); return e ? atoi(e) : 0; }();
+    const int cw = cw_env ? cw_env : (PERP ? HSLO_CW_V : HSLO_CW_H);
+    if (cw == 8) hslo_lines_cw<PERP, 8>(a, nviews, T, P1, P2, D, zd, nlines, len);
+    else if (cw == 16) hslo_lines_cw<PERP, 16>(a, nviews, T, P1, P2, D, zd, nlines, len);
+    else hslo_lines_cw<PERP, 32>(a, nviews, T, P1, P2, D, zd, nlines, len);
+}
+
+// Scanline optimisation + WTA for 1 or 2 views.
 // img_a[v] = the view's own image, img_b[v] = the other image; osign[v] = +1 (left view) / -1 (right view).
-// Scratch from the current Workspace scope: (4 D + 2) H W floats per view.
+// Scratch from the current Workspace scope, per view: 5 quad volumes (6 when the input is not already in quads)
+// + 4 planes.
 void launch_hslo_wta(int nviews, const Vol *cost, const u8 *const *img_a, const u8 *const *img_b, const int *osign,
                      float *const *disp, float *const *vol_out, float T, float H1, float H2, int D, int zd, int H, int W,
                      int elem_sz)
@@ -242,37 +337,51 @@ void launch_hslo_wta(int nviews, const Vol *cost, const u8 *const *img_a, const 
     const float P1[3] = {H1, (float)((double)H1 / 4.0), (float)((double)H1 / 10.0)}; // d_dc_hslo.cu:124-127
     const float P2[3] = {H2, (float)((double)H2 / 4.0), (float)((double)H2 / 10.0)};
     const size_t HW = (size_t)H * W;
-    if (D > 256 || nviews < 1 || nviews > 2 || (nviews == 2 && cost[0].quad != cost[1].quad)) {
-        fail("hslo: num_disp > 256 or bad view count / layouts", "D", __FILE__, __LINE__);
+    const int NQ = (D + 3) / 4;
+    const size_t VQ = (size_t)NQ * HW; // float4 elements of one quad volume
+    if (D > 256 || D < 1 || nviews < 1 || nviews > 2) {
+        fail("hslo: num_disp must be 1..256 and views 1..2", "D", __FILE__, __LINE__);
         return;
     }
     ProfScope p("hslo");
-    HsloArgs a;
+    HsloLineArgs ah, av;
+    HsloCombineArgs ac;
     for (int v = 0; v < 2; ++v) {
         const int s = v < nviews ? v : 0;
-        a.cost[v] = cost[s];
-        a.osign[v] = osign[s];
-        if (v < nviews) {
-            a.out[v] = Workspace::get<float>(4 * (size_t)((D + 3) / 4) * 4 * HW);
-            float *av = Workspace::get<float>(2 * HW);
-            a.avg_a[v] = av;
-            a.avg_b[v] = av + HW;
-            hipLaunchKernelGGL(stm_k_hslo_avg, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream(), img_a[s], img_b[s], av,
-                               av + HW, HW, elem_sz);
-            STM_CHECK_LAUNCH();
-        } else {
-            a.out[v] = a.out[0]; a.avg_a[v] = a.avg_a[0]; a.avg_b[v] = a.avg_b[0];
+        ah.osign[v] = av.osign[v] = osign[s];
+        if (v >= nviews) {
+            ah.cost[v] = ah.cost[0]; ah.out[v] = ah.out[0]; ah.avg_a[v] = ah.avg_a[0]; ah.avg_b[v] = ah.avg_b[0];
+            av.cost[v] = av.cost[0]; av.out[v] = av.out[0]; av.avg_a[v] = av.avg_a[0]; av.avg_b[v] = av.avg_b[0];
+            ac.out_h[v] = ac.out_h[0]; ac.out_v[v] = ac.out_v[0]; ac.disp[v] = ac.disp[0]; ac.vol[v] = ac.vol[0];
+            continue;
         }
+        float *planes = Workspace::get<float>(4 * HW);
+        hipLaunchKernelGGL(stm_k_hslo_avg, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), img_a[s], img_b[s], planes, planes + HW,
+                           planes + 2 * HW, planes + 3 * HW, H, W, elem_sz);
+        STM_CHECK_LAUNCH();
+        const float4 *cq;
+        if (cost[s].quad) cq = (const float4 *)cost[s].base;
+        else {
+            float4 *conv = Workspace::get<float4>(VQ);
+            hipLaunchKernelGGL(stm_k_to_quads, dim3((unsigned)((HW + 255) / 256), NQ), dim3(256), 0, stream(), cost[s], conv, D, HW);
+            STM_CHECK_LAUNCH();
+            cq = conv;
+        }
+        float4 *ct = Workspace::get<float4>(VQ);
+        hipLaunchKernelGGL(stm_k_transpose_quads, dim3(cdiv(W, 32), cdiv(H, 32), NQ), dim3(256), 0, stream(), cq, ct, H, W);
+        STM_CHECK_LAUNCH();
+        float4 *oh = Workspace::get<float4>(2 * VQ), *ov = Workspace::get<float4>(2 * VQ);
+        ah.cost[v] = cq; ah.out[v] = oh; ah.avg_a[v] = planes; ah.avg_b[v] = planes + HW;
+        av.cost[v] = ct; av.out[v] = ov; av.avg_a[v] = planes + 2 * HW; av.avg_b[v] = planes + 3 * HW;
+        ac.out_h[v] = oh; ac.out_v[v] = ov; ac.disp[v] = disp[s]; ac.vol[v] = vol_out ? vol_out[s] : nullptr;
     }
-    if (D <= 64) hslo_launch<1>(a, nviews, T, P1, P2, D, zd, H, W);
-    else if (D <= 128) hslo_launch<2>(a, nviews, T, P1, P2, D, zd, H, W);
-    else hslo_launch<4>(a, nviews, T, P1, P2, D, zd, H, W);
-    hipLaunchKernelGGL(stm_k_hslo_combine_wta, dim3((unsigned)((HW + 255) / 256), nviews), dim3(256), 0, stream(), a, disp[0],
-                       nviews > 1 ? disp[1] : disp[0], vol_out ? vol_out[0] : nullptr,
-                       (vol_out && nviews > 1) ? vol_out[1] : nullptr, D, zd, HW);
+    hslo_lines<false>(ah, nviews, T, P1, P2, D, zd, H, W); // left->right and right->left
+    hslo_lines<true>(av, nviews, T, P1, P2, D, zd, W, H);  // top->bottom and bottom->top on the transposed volume
+    hipLaunchKernelGGL(stm_k_hslo_combine_wta, dim3(cdiv(W, 32), cdiv(H, 32), nviews), dim3(256), 0, stream(), ac, D, zd, H, W);
     STM_CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------ misc volume op kept for the per-stage API
 __global__ __launch_bounds__(256) void stm_k_scale_volume(Vol v, float s, int D, size_t HW)
 {
     size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
