@@ -27,6 +27,10 @@
  * Errors: like the reference (cuda_utils.h:12-21) a HIP failure prints a message and
  * calls exit(1); unlike it, kernel launches are checked too.  stm_set_error_mode(1)
  * turns that into "record and return" for embedding hosts (query stm_last_error()).
+ * Arguments the reference would turn into undefined behaviour are errors of the same kind:
+ * a dimension < 1, elem_sz < 3 (three channels of every element are read), num_views < 2
+ * for the interlacer (d_mux_multiview.cu:62-66 reads views[1]), an angle whose row period
+ * round(num_views / tan(angle) / elem_sz) is 0 (ty % 0, :55), num_cols > 8192 in ca_cross.
  *
  * All file:line citations are relative to the reference repository root.
  */

@@ -2,6 +2,7 @@
 // and the device-resident frame pipeline.  Mirrors the reference's per-stage host API
 // (SURVEY.md section 8b); each function cites the reference wrapper it replaces.
 #include "stm_common.h"
+#include <initializer_list>
 #include "../../include/stm_hip.h"
 
 #include <map>
@@ -79,6 +80,22 @@ void down_planes(float **planes, const float *slab, int D, size_t HW)
 struct Arms {
     u8 *up, *down, *left, *right;
 };
+
+// Argument screen shared by every entry point.  The reference checks nothing (a zero-sized launch or an
+// out-of-range view index is undefined behaviour there); here such calls fail like any other error (stm_hip.h).
+struct Dim { const char *name; int v, lo; };
+bool args_ok(const char *fn, std::initializer_list<Dim> dims)
+{
+    for (const Dim &d : dims)
+        if (d.v < d.lo) {
+            char msg[160];
+            snprintf(msg, sizeof msg, "%s: %s = %d, must be >= %d", fn, d.name, d.v, d.lo);
+            fail(msg, d.name, __FILE__, __LINE__);
+            return false;
+        }
+    return true;
+}
+
 
 // ---------------------------------------------------------------- device cores
 // cost init: pack -> census -> fused AD + census + robust combine
@@ -162,6 +179,9 @@ void stm_d_ci_adcensus(unsigned char *d_img_l, unsigned char *d_img_r, float **d
                        float *d_adcensus_cost_memory, float ad_coeff, float census_coeff, int num_disp, int zero_disp,
                        int num_rows, int num_cols, int elem_sz)
 {
+    if (!args_ok("d_ci_adcensus", {{"num_disp", num_disp, 1}, {"num_rows", num_rows, 1}, {"num_cols", num_cols, 1},
+                                   {"elem_sz", elem_sz, 3}}))
+        return;
     size_t HW = (size_t)num_rows * num_cols, V = HW * num_disp;
     Workspace::begin(4 * HW * 4 + 4096);
     for (int d = 0; d < num_disp; ++d) { // d_ci_adcensus.cu:150-157
@@ -178,6 +198,9 @@ void stm_d_ci_adcensus(unsigned char *d_img_l, unsigned char *d_img_r, float **d
 void stm_ci_adcensus(unsigned char *img_l, unsigned char *img_r, float **cost_l, float **cost_r, float ad_coeff,
                      float census_coeff, int num_disp, int zero_disp, int num_rows, int num_cols, int elem_sz)
 {
+    if (!args_ok("ci_adcensus", {{"num_disp", num_disp, 1}, {"num_rows", num_rows, 1}, {"num_cols", num_cols, 1},
+                                 {"elem_sz", elem_sz, 3}}))
+        return;
     size_t HW = (size_t)num_rows * num_cols, V = HW * num_disp;
     Workspace::begin(2 * V * 4 + 2 * HW * elem_sz + 4 * HW * 4 + 8192);
     u8 *dl = up(img_l, HW * elem_sz), *dr = up(img_r, HW * elem_sz);
@@ -195,6 +218,9 @@ void stm_d_ca_cross(unsigned char *d_img, float **d_cost, float **d_acost, float
                     unsigned char **d_cross, float ucd, float lcd, int usd, int lsd, int num_disp, int num_rows,
                     int num_cols, int elem_sz)
 {
+    if (!args_ok("d_ca_cross", {{"num_disp", num_disp, 1}, {"num_rows", num_rows, 1}, {"num_cols", num_cols, 1},
+                                {"elem_sz", elem_sz, 3}}))
+        return;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(HW * 4 + 4096);
     for (int d = 0; d < num_disp; ++d) h_acost[d] = d_acost_memory + (size_t)d * HW; // d_ca_cross.cu:207-210
@@ -209,6 +235,9 @@ void stm_d_ca_cross(unsigned char *d_img, float **d_cost, float **d_acost, float
 void stm_ca_cross(unsigned char *img, unsigned char **cross, float **cost, float **acost, float ucd, float lcd, int usd,
                   int lsd, int num_disp, int num_rows, int num_cols, int elem_sz)
 {
+    if (!args_ok("ca_cross", {{"num_disp", num_disp, 1}, {"num_rows", num_rows, 1}, {"num_cols", num_cols, 1},
+                              {"elem_sz", elem_sz, 3}}))
+        return;
     size_t HW = (size_t)num_rows * num_cols, V = HW * num_disp;
     Workspace::begin(2 * V * 4 + HW * elem_sz + 8 * HW + 8192);
     u8 *dimg = up(img, HW * elem_sz);
@@ -227,10 +256,12 @@ void stm_ca_cross(unsigned char *img, unsigned char **cross, float **cost, float
 // =============================================================== disparity selection
 void stm_d_dc_wta(float **d_cost, float *d_disp, int num_disp, int zero_disp, int num_rows, int num_cols)
 {
+    if (!args_ok("d_dc_wta", {{"num_disp", num_disp, 1}, {"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}})) return;
     launch_wta(vol_table(d_cost), d_disp, num_disp, zero_disp, num_rows, num_cols);
 }
 void stm_dc_wta(float **cost, float *disp, int num_disp, int zero_disp, int num_rows, int num_cols)
 {
+    if (!args_ok("dc_wta", {{"num_disp", num_disp, 1}, {"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}})) return;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin((size_t)num_disp * HW * 4 + HW * 4 + 4096);
     float *c = up_planes(cost, num_disp, HW);
@@ -243,6 +274,9 @@ void stm_dc_wta(float **cost, float *disp, int num_disp, int zero_disp, int num_
 void stm_d_dc_hslo(float **d_cost, float *d_disp, unsigned char *d_img_l, unsigned char *d_img_r, float T, float H1,
                    float H2, int num_disp, int zero_disp, int num_rows, int num_cols, int elem_sz)
 {
+    if (!args_ok("d_dc_hslo", {{"num_disp", num_disp, 1}, {"num_rows", num_rows, 1}, {"num_cols", num_cols, 1},
+                               {"elem_sz", elem_sz, 3}}))
+        return;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin((size_t)((num_disp + 3) / 4) * HW * 16 * 6 + 16 * HW + 16384);
     Vol c = vol_table(d_cost);
@@ -254,6 +288,9 @@ void stm_d_dc_hslo(float **d_cost, float *d_disp, unsigned char *d_img_l, unsign
 void stm_dc_hslo(float **cost, float *disp, unsigned char *img_l, unsigned char *img_r, float T, float H1, float H2,
                  int num_disp, int zero_disp, int num_rows, int num_cols, int elem_sz)
 {
+    if (!args_ok("dc_hslo", {{"num_disp", num_disp, 1}, {"num_rows", num_rows, 1}, {"num_cols", num_cols, 1},
+                             {"elem_sz", elem_sz, 3}}))
+        return;
     size_t HW = (size_t)num_rows * num_cols, V = HW * num_disp;
     Workspace::begin(V * 4 + (size_t)((num_disp + 3) / 4) * HW * 16 * 6 + 2 * HW * elem_sz + 5 * HW * 4 + 32768);
     float *c = up_planes(cost, num_disp, HW);
@@ -272,6 +309,7 @@ void stm_dc_hslo(float **cost, float *disp, unsigned char *img_l, unsigned char 
 void stm_d_dr_dcc(unsigned char *d_outliers_l, unsigned char *d_outliers_r, float *d_disp_l, float *d_disp_r, int num_rows,
                   int num_cols)
 {
+    if (!args_ok("d_dr_dcc", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}})) return;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(2 * HW + 1024);
     u8 *hl = Workspace::get<u8>(HW), *hr = Workspace::get<u8>(HW);
@@ -280,6 +318,7 @@ void stm_d_dr_dcc(unsigned char *d_outliers_l, unsigned char *d_outliers_r, floa
 void stm_dr_dcc(unsigned char *outliers_l, unsigned char *outliers_r, float *disp_l, float *disp_r, int num_rows,
                 int num_cols)
 {
+    if (!args_ok("dr_dcc", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}})) return;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(12 * HW + 4096);
     float *dl = up(disp_l, HW), *dr = up(disp_r, HW);
@@ -294,6 +333,7 @@ void stm_dr_dcc(unsigned char *outliers_l, unsigned char *outliers_r, float *dis
 void stm_d_dr_irv(float *d_disp, unsigned char *d_outliers, unsigned char **d_cross, int thresh_s, float thresh_h,
                   int num_rows, int num_cols, int num_disp, int zero_disp, int usd, int iterations)
 {
+    if (!args_ok("d_dr_irv", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}, {"num_disp", num_disp, 1}})) return;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(20 * HW + 8192);
     Arms a = arms_from_table(d_cross);
@@ -305,6 +345,7 @@ void stm_d_dr_irv(float *d_disp, unsigned char *d_outliers, unsigned char **d_cr
 void stm_dr_irv(float *disp, unsigned char *outliers, unsigned char **cross, int thresh_s, float thresh_h, int num_rows,
                 int num_cols, int num_disp, int zero_disp, int usd, int iterations)
 {
+    if (!args_ok("dr_irv", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}, {"num_disp", num_disp, 1}})) return;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(28 * HW + 16384);
     float *d = up(disp, HW);
@@ -321,12 +362,18 @@ void stm_dr_irv(float *disp, unsigned char *outliers, unsigned char **cross, int
 void stm_d_filter_bilateral_1(float *d_img, int radius, float sigma_color, float sigma_spatial, int num_rows, int num_cols,
                               int num_disp)
 {
+    if (!args_ok("d_filter_bilateral_1", {{"radius", radius, 0}, {"num_rows", num_rows, 1}, {"num_cols", num_cols, 1},
+                                          {"num_disp", num_disp, 1}}))
+        return;
     Workspace::begin((size_t)num_rows * num_cols * 4 + 1024);
     core_bilateral(d_img, radius, sigma_color, sigma_spatial, num_rows, num_cols, num_disp);
 }
 void stm_filter_bilateral_1(float *img, int radius, float sigma_color, float sigma_spatial, int num_rows, int num_cols,
                             int num_disp)
 {
+    if (!args_ok("filter_bilateral_1", {{"radius", radius, 0}, {"num_rows", num_rows, 1}, {"num_cols", num_cols, 1},
+                                        {"num_disp", num_disp, 1}}))
+        return;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(8 * HW + 4096);
     float *d = up(img, HW);
@@ -337,6 +384,7 @@ void stm_filter_bilateral_1(float *img, int radius, float sigma_color, float sig
 
 void stm_d_filter_gaussian_1(float *d_img, int radius, float sigma_spatial, int num_rows, int num_cols)
 {
+    if (!args_ok("d_filter_gaussian_1", {{"radius", radius, 0}, {"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}})) return;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(HW * 4 + 1024);
     float *tmp = Workspace::get<float>(HW);
@@ -345,6 +393,7 @@ void stm_d_filter_gaussian_1(float *d_img, int radius, float sigma_spatial, int 
 }
 void stm_filter_gaussian_1(float *img, int radius, float sigma_spatial, int num_rows, int num_cols)
 {
+    if (!args_ok("filter_gaussian_1", {{"radius", radius, 0}, {"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}})) return;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(8 * HW + 4096);
     float *d = up(img, HW), *tmp = Workspace::get<float>(HW);
@@ -355,6 +404,7 @@ void stm_filter_gaussian_1(float *img, int radius, float sigma_spatial, int num_
 
 void stm_d_filter_bleed_1(unsigned char *d_img, int radius, int num_rows, int num_cols)
 {
+    if (!args_ok("d_filter_bleed_1", {{"radius", radius, 0}, {"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}})) return;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(HW + 1024);
     u8 *tmp = Workspace::get<u8>(HW);
@@ -363,6 +413,7 @@ void stm_d_filter_bleed_1(unsigned char *d_img, int radius, int num_rows, int nu
 }
 void stm_filter_bleed_1(unsigned char *img, int radius, int num_rows, int num_cols)
 {
+    if (!args_ok("filter_bleed_1", {{"radius", radius, 0}, {"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}})) return;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(2 * HW + 4096);
     u8 *d = up(img, HW), *tmp = Workspace::get<u8>(HW);
@@ -375,10 +426,12 @@ void stm_filter_bleed_1(unsigned char *img, int radius, int num_rows, int num_co
 void stm_d_dibr_occl(unsigned char *d_occl_l, unsigned char *d_occl_r, float *d_disp_l, float *d_disp_r, int num_rows,
                      int num_cols)
 {
+    if (!args_ok("d_dibr_occl", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}})) return;
     launch_occl(d_occl_l, d_occl_r, d_disp_l, d_disp_r, num_rows, num_cols);
 }
 void stm_dibr_occl(unsigned char *occl_l, unsigned char *occl_r, float *disp_l, float *disp_r, int num_rows, int num_cols)
 {
+    if (!args_ok("dibr_occl", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}})) return;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(10 * HW + 4096);
     float *dl = up(disp_l, HW), *dr = up(disp_r, HW);
@@ -391,11 +444,13 @@ void stm_dibr_occl(unsigned char *occl_l, unsigned char *occl_r, float *disp_l, 
 void stm_d_dibr_occl_to_mask(float *d_mask_l, float *d_mask_r, unsigned char *d_occl_l, unsigned char *d_occl_r,
                              int num_rows, int num_cols)
 {
+    if (!args_ok("d_dibr_occl_to_mask", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}})) return;
     launch_occl_to_mask(d_mask_l, d_mask_r, d_occl_l, d_occl_r, num_rows, num_cols);
 }
 void stm_dibr_occl_to_mask(float *mask_l, float *mask_r, unsigned char *occl_l, unsigned char *occl_r, int num_rows,
                            int num_cols)
 {
+    if (!args_ok("dibr_occl_to_mask", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}})) return;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(10 * HW + 4096);
     u8 *ol = up(occl_l, HW), *orr = up(occl_r, HW);
@@ -409,6 +464,7 @@ void stm_d_dibr_dbm(unsigned char *d_img_out, unsigned char *d_img_in_l, unsigne
                     float *d_disp_r, unsigned char *d_occl_l, unsigned char *d_occl_r, float *d_mask_l, float *d_mask_r,
                     float shift, int num_rows, int num_cols, int elem_sz)
 {
+    if (!args_ok("d_dibr_dbm", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}, {"elem_sz", elem_sz, 3}})) return;
     (void)d_occl_l; (void)d_occl_r; // unused by the reference too (d_dibr_bwarp.cu:24-70)
     Workspace::begin((size_t)num_rows * num_cols * 4 + 1024);
     core_dbm(d_img_out, d_img_in_l, d_img_in_r, d_disp_l, d_disp_r, d_mask_l, d_mask_r, shift, num_rows, num_cols, elem_sz,
@@ -418,6 +474,7 @@ void stm_dibr_dbm(unsigned char *img_out, unsigned char *img_in_l, unsigned char
                   unsigned char *occl_l, unsigned char *occl_r, float *mask_l, float *mask_r, float shift, int num_rows,
                   int num_cols, int elem_sz)
 {
+    if (!args_ok("dibr_dbm", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}, {"elem_sz", elem_sz, 3}})) return;
     (void)occl_l; (void)occl_r;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(3 * HW * elem_sz + 20 * HW + 8192);
@@ -431,6 +488,7 @@ void stm_dibr_dbm(unsigned char *img_out, unsigned char *img_in_l, unsigned char
 void stm_d_dibr_dfm(unsigned char *d_img_out, unsigned char *d_img_in_l, unsigned char *d_img_in_r, float *d_disp_l,
                     float *d_disp_r, float shift, int num_rows, int num_cols, int elem_sz)
 {
+    if (!args_ok("d_dibr_dfm", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}, {"elem_sz", elem_sz, 3}})) return;
     (void)d_img_in_r; (void)d_disp_r; // the right warp is computed and discarded in the reference (A-Q23)
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(HW * 8 + 1024);
@@ -440,6 +498,7 @@ void stm_d_dibr_dfm(unsigned char *d_img_out, unsigned char *d_img_in_l, unsigne
 void stm_dibr_dfm(unsigned char *img_out, unsigned char *img_in_l, unsigned char *img_in_r, float *disp_l, float *disp_r,
                   float shift, int num_rows, int num_cols, int elem_sz)
 {
+    if (!args_ok("dibr_dfm", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}, {"elem_sz", elem_sz, 3}})) return;
     (void)img_in_r; (void)disp_r;
     size_t HW = (size_t)num_rows * num_cols;
     Workspace::begin(2 * HW * elem_sz + 12 * HW + 8192);
@@ -455,11 +514,17 @@ void stm_dibr_dfm(unsigned char *img_out, unsigned char *img_in_l, unsigned char
 void stm_d_mux_multiview(unsigned char **d_views, unsigned char *d_out_data, int num_views, float angle, int in_rows,
                          int in_cols, int out_rows, int out_cols, int elem_sz)
 {
+    if (!args_ok("d_mux_multiview", {{"num_views", num_views, 2}, {"in_rows", in_rows, 1}, {"in_cols", in_cols, 1},
+                                     {"out_rows", out_rows, 1}, {"out_cols", out_cols, 1}, {"elem_sz", elem_sz, 3}}))
+        return;
     core_mux((const u8 *const *)d_views, d_out_data, num_views, angle, in_rows, in_cols, out_rows, out_cols, elem_sz, 2); // :148-151
 }
 void stm_mux_multiview(unsigned char **views, unsigned char *out_data, int num_views, float angle, int in_rows, int in_cols,
                        int out_rows, int out_cols, int elem_sz)
 {
+    if (!args_ok("mux_multiview", {{"num_views", num_views, 2}, {"in_rows", in_rows, 1}, {"in_cols", in_cols, 1},
+                                   {"out_rows", out_rows, 1}, {"out_cols", out_cols, 1}, {"elem_sz", elem_sz, 3}}))
+        return;
     size_t in_sz = (size_t)in_rows * in_cols * elem_sz, out_sz = (size_t)out_rows * out_cols * elem_sz;
     Workspace::begin(num_views * (in_sz + 256) + out_sz + 8192);
     std::vector<u8 *> h(num_views);
@@ -478,6 +543,9 @@ void stm_mux_multiview(unsigned char **views, unsigned char *out_data, int num_v
 void stm_d_demux_sbs(unsigned char *d_img_l, unsigned char *d_img_r, unsigned char *d_img_sbs, int num_rows,
                      int num_cols_sbs, int num_cols_out, int elem_sz)
 {
+    if (!args_ok("d_demux_sbs", {{"num_rows", num_rows, 1}, {"num_cols_sbs", num_cols_sbs, 1},
+                                 {"num_cols_out", num_cols_out, 1}, {"elem_sz", elem_sz, 3}}))
+        return;
     launch_demux_sbs(d_img_l, d_img_r, d_img_sbs, num_rows, num_cols_sbs, num_cols_out, elem_sz);
 }
 
@@ -578,6 +646,11 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
                         int num_views, float angle, int num_disp, int zero_disp, float ad_coeff, float census_coeff,
                         float ucd, float lcd, int usd, int lsd, int thresh_s, float thresh_h, int stages)
 {
+    if (!args_ok("d_adcensus_stm", {{"num_rows", num_rows, 1}, {"num_cols_sbs", num_cols_sbs, 1},
+                                    {"num_cols", num_cols, 1}, {"num_rows_out", num_rows_out, 1},
+                                    {"num_cols_out", num_cols_out, 1}, {"elem_sz", elem_sz, 3},
+                                    {"num_views", num_views, 2}, {"num_disp", num_disp, 1}}))
+        return;
     const int H = num_rows, W = num_cols, N = num_views;
     const size_t HW = (size_t)H * W, IMG = HW * elem_sz;
     const size_t V = HW * (size_t)((num_disp + 3) / 4) * 4;
@@ -602,6 +675,12 @@ void stm_d_adcensus_stm_2(unsigned char *d_img_sbs, float *d_disp_l, float *d_di
                           int num_disp, int zero_disp, float ad_coeff, float census_coeff, float ucd, float lcd, int usd,
                           int lsd, int thresh_s, float thresh_h)
 {
+    if (!args_ok("d_adcensus_stm_2", {{"num_rows", num_rows, 1}, {"num_cols_sbs", num_cols_sbs, 1},
+                                      {"num_cols", num_cols, 1}, {"num_rows_out", num_rows_out, 1},
+                                      {"num_cols_out", num_cols_out, 1}, {"num_rows_disp", num_rows_disp, 1},
+                                      {"num_cols_disp", num_cols_disp, 1}, {"elem_sz", elem_sz, 3},
+                                      {"num_views", num_views, 2}, {"num_disp", num_disp, 1}}))
+        return;
     const int H = num_rows, W = num_cols, h = num_rows_disp, w = num_cols_disp, N = num_views;
     const size_t HW = (size_t)H * W, IMG = HW * elem_sz, hw = (size_t)h * w;
     const size_t V = hw * (size_t)((num_disp + 3) / 4) * 4;
@@ -627,6 +706,12 @@ void stm_adcensus_stm_2(unsigned char *img_sbs, float *disp_l, float *disp_r, un
                         int zero_disp, float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
                         int thresh_s, float thresh_h)
 {
+    if (!args_ok("adcensus_stm_2", {{"num_rows", num_rows, 1}, {"num_cols_sbs", num_cols_sbs, 1},
+                                    {"num_cols", num_cols, 1}, {"num_rows_out", num_rows_out, 1},
+                                    {"num_cols_out", num_cols_out, 1}, {"num_rows_disp", num_rows_disp, 1},
+                                    {"num_cols_disp", num_cols_disp, 1}, {"elem_sz", elem_sz, 3},
+                                    {"num_views", num_views, 2}, {"num_disp", num_disp, 1}}))
+        return;
     size_t HW = (size_t)num_rows * num_cols, sbs_sz = (size_t)num_rows * num_cols_sbs * elem_sz;
     size_t out_sz = (size_t)num_rows_out * num_cols_out * elem_sz;
     u8 *d_sbs, *d_out;
@@ -649,6 +734,9 @@ void stm_adcensus_stm_2(unsigned char *img_sbs, float *disp_l, float *disp_r, un
 void stm_d_tx_scale(unsigned char *img_in, unsigned char *img_out, int in_rows, int in_cols, int out_rows, int out_cols,
                     int elem_sz)
 {
+    if (!args_ok("d_tx_scale", {{"in_rows", in_rows, 1}, {"in_cols", in_cols, 1}, {"out_rows", out_rows, 1},
+                                {"out_cols", out_cols, 1}, {"elem_sz", elem_sz, 3}}))
+        return;
     size_t in_sz = (size_t)in_rows * in_cols * elem_sz, out_sz = (size_t)out_rows * out_cols * elem_sz;
     Workspace::begin(in_sz + out_sz + 4096);
     u8 *di = up(img_in, in_sz), *dout = Workspace::get<u8>(out_sz);
@@ -662,6 +750,10 @@ void stm_adcensus_stm(unsigned char *img_sbs, float *disp_l, float *disp_r, unsi
                       float angle, int num_disp, int zero_disp, float ad_coeff, float census_coeff, float ucd, float lcd,
                       int usd, int lsd, int thresh_s, float thresh_h)
 {
+    if (!args_ok("adcensus_stm", {{"num_rows", num_rows, 1}, {"num_cols_sbs", num_cols_sbs, 1}, {"num_cols", num_cols, 1},
+                                  {"num_rows_out", num_rows_out, 1}, {"num_cols_out", num_cols_out, 1},
+                                  {"elem_sz", elem_sz, 3}, {"num_views", num_views, 2}, {"num_disp", num_disp, 1}}))
+        return;
     size_t HW = (size_t)num_rows * num_cols, sbs_sz = (size_t)num_rows * num_cols_sbs * elem_sz;
     size_t out_sz = (size_t)num_rows_out * num_cols_out * elem_sz;
     // own buffers come from plain hipMalloc: the pipeline call below re-carves the workspace

@@ -411,6 +411,13 @@ def test_error_mode_records_instead_of_exiting(gpu_ready, stm):
         cost = np.zeros((1, 2, 8200), np.float32)
         host_api.ca_cross(L, cost, 6.0, 20.0, 3, 1)  # num_cols > 8192 is rejected by the row-tile kernel
         assert b"8192" in lib.stm_last_error()
+        views = np.zeros((2, 4, 4, 3), np.uint8)
+        host_api.mux_multiview([views[0], views[1]], 80.0, 4, 4)  # round(N / tan(angle) / 3) == 0: `ty % 0` in d_mux_multiview.cu:55
+        assert b"y_interval" in lib.stm_last_error()
+        host_api.mux_multiview([views[0]], 18.43, 4, 4)             # one view: views[1] is read (:62-66)
+        assert b"num_views = 1" in lib.stm_last_error()
+        host_api.dc_wta(np.zeros((0, 4, 4), np.float32), 0)         # no hypotheses
+        assert b"num_disp = 0" in lib.stm_last_error()
     finally:
         lib.stm_set_error_mode(0)
 
@@ -529,3 +536,53 @@ def test_image_cli_matches_stage_chain(gpu_ready, orc, golden, tmp_path):
     want = orc.mux_multiview(views, 18.43, H, W, 2)
     assert np.array_equal(bmp_io.read_bmp(str(out / "interlaced.bmp")), want)
     assert np.array_equal(bmp_io.read_bmp(str(out / "view_3.bmp")), views[3])
+
+
+def _fuzz_cases(n, seed):
+    rng = np.random.RandomState(seed)
+    cases = []
+    for i in range(n):
+        H = int(rng.randint(1, 90))
+        W = int(rng.randint(2, 140))
+        D = int(rng.randint(1, 41))
+        zd = int(rng.randint(0, D)) if rng.rand() < 0.85 else int(rng.randint(-3, D + 4))
+        usd = int(rng.randint(1, 41))
+        lsd = int(rng.randint(1, usd + 1))
+        views = int(rng.randint(2, 10))
+        angle = float(rng.choice([18.43, -18.43, 45.0, 7.0, 60.0, 30.0]))
+        if round(views / np.tan(np.radians(abs(angle))) / 3.0) < 1:   # row period 0: rejected input, tested elsewhere
+            angle = 18.43
+        cases.append(dict(H=H, W=W, D=D, zd=zd, usd=usd, lsd=lsd, ucd=float(rng.choice([0.0, 4.0, 6.0, 15.5, 60.0])),
+                          lcd=float(rng.choice([0.0, 10.0, 20.0, 33.25, 255.0])), views=views, angle=angle,
+                          ad=float(rng.choice([1.0, 10.0, 25.0])), cen=float(rng.choice([5.0, 30.0, 64.0])),
+                          ts=int(rng.randint(0, 40)), th=float(rng.choice([0.0, 0.2, 0.4, 0.9, 1.5])),
+                          noise=bool(rng.rand() < 0.4), seed=int(rng.randint(1, 1 << 30))))
+    return cases
+
+
+@pytest.mark.parametrize("c", _fuzz_cases(28, 20261004), ids=lambda c: "%dx%d_D%d" % (c["H"], c["W"], c["D"]))
+def test_random_frames_and_parameters(gpu_ready, orc, c):
+    """Seeded sweep over shapes and every parameter of adcensus_stm (d_io.h:32-40): ragged sizes, 2..9 views,
+    zero_disp outside [0, D), zero / huge colour thresholds, pure-noise pairs (every pixel an outlier)."""
+    import torch
+    from stm_amd import device_api as dev, synth
+    H, W, D, zd = c["H"], c["W"], c["D"], c["zd"]
+    if c["noise"]:
+        L, R = rand_pair(max(H, 8), max(W, 8), c["seed"])
+        sbs = np.ascontiguousarray(np.concatenate([L[:H, :W], R[:H, :W]], axis=1))
+    else:
+        sbs, _ = synth.sbs_frame(H, W, D, min(max(zd, 0), D - 1), seed=c["seed"])
+    assert sbs.shape == (H, 2 * W, 3)
+    p = dev.FrameParams(num_disp=D, zero_disp=zd, num_views=c["views"], angle=c["angle"], ad_coeff=c["ad"],
+                        census_coeff=c["cen"], ucd=c["ucd"], lcd=c["lcd"], usd=c["usd"], lsd=c["lsd"],
+                        thresh_s=c["ts"], thresh_h=c["th"])
+    d_sbs = torch.from_numpy(sbs).cuda()
+    dl = torch.zeros(H, W, dtype=torch.float32, device="cuda")
+    dr = torch.zeros_like(dl)
+    out = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+    dev.d_adcensus_stm(d_sbs, dl, dr, out, p, stages=3)
+    torch.cuda.synchronize()
+    want = orc.adcensus_stm(sbs, H, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd, p.usd,
+                            p.lsd, p.thresh_s, p.thresh_h)
+    assert np.array_equal(dl.cpu().numpy(), want["disp_l"]) and np.array_equal(dr.cpu().numpy(), want["disp_r"])
+    assert np.array_equal(out.cpu().numpy(), want["interlaced"])
