@@ -62,6 +62,9 @@ void d_filter_gaussian_1(float* d_img, int radius, float sigma_spatial, int num_
 // d_filter.h:22-28
 void d_filter_bleed_1(unsigned char* d_img, int radius, int num_rows, int num_cols);
 void filter_bleed_1(unsigned char* img, int radius, int num_rows, int num_cols);
+// d_filter.h:11-16
+void filter_median(float* img, int num_rows, int num_cols);
+void d_filter_median(float* d_img_in, int num_rows, int num_cols);
 // d_dibr_occl.h:14-33
 void d_dibr_occl_to_mask(float* d_mask_l, float* d_mask_r, unsigned char* d_occl_l, unsigned char* d_occl_r,
                          int num_rows, int num_cols);

@@ -127,6 +127,10 @@ void stm_d_filter_gaussian_1(float *d_img, int radius, float sigma_spatial, int 
 /* d_filter.h:22-28  (d_filter.cu:105-167 and following) */
 void stm_filter_bleed_1(unsigned char *img, int radius, int num_rows, int num_cols);
 void stm_d_filter_bleed_1(unsigned char *d_img, int radius, int num_rows, int num_cols);
+/* d_filter.h:11-16  (d_filter.cu:7-103): 3x3 "median" on int-truncated values; unused by the reference's
+ * drivers (image_io.cpp:239-240 are commented out) but part of its stage API */
+void stm_filter_median(float *img, int num_rows, int num_cols);
+void stm_d_filter_median(float *d_img, int num_rows, int num_cols);
 
 /* --------------------------------------------------------------- DIBR (a18-a23) */
 /* d_dibr_occl.h:27-33  (d_dibr_occl.cu:130-218) */

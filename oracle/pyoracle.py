@@ -202,6 +202,13 @@ def filter_gaussian_1(img, radius, sigma):
     return img
 
 
+def filter_median(img):
+    H, W = img.shape
+    img = np.array(img, dtype=np.float32, order="C", copy=True)
+    lib().orc_filter_median(img.ctypes.data_as(f32p), H, W)
+    return img
+
+
 def filter_bleed_1(img, radius):
     H, W = img.shape
     img = np.array(img, dtype=np.uint8, order="C", copy=True)

@@ -422,6 +422,27 @@ void stm_filter_bleed_1(unsigned char *img, int radius, int num_rows, int num_co
     sync();
 }
 
+// d_filter.cu:47-103
+void stm_d_filter_median(float *d_img, int num_rows, int num_cols)
+{
+    if (!args_ok("d_filter_median", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}})) return;
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(HW * 4 + 1024);
+    float *tmp = Workspace::get<float>(HW);
+    launch_median3(d_img, tmp, num_rows, num_cols);
+    STM_CHECK(hipMemcpyAsync(d_img, tmp, HW * 4, hipMemcpyDeviceToDevice, stream())); // d_filter.cu:67
+}
+void stm_filter_median(float *img, int num_rows, int num_cols)
+{
+    if (!args_ok("filter_median", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}})) return;
+    size_t HW = (size_t)num_rows * num_cols;
+    Workspace::begin(8 * HW + 4096);
+    float *d = up(img, HW), *tmp = Workspace::get<float>(HW);
+    launch_median3(d, tmp, num_rows, num_cols);
+    down(img, tmp, HW);
+    sync();
+}
+
 // =============================================================== DIBR
 void stm_d_dibr_occl(unsigned char *d_occl_l, unsigned char *d_occl_r, float *d_disp_l, float *d_disp_r, int num_rows,
                      int num_cols)

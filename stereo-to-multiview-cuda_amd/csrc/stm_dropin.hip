@@ -28,6 +28,8 @@ void filter_gaussian_1(float* a, int b, float c, int d, int e) { stm_filter_gaus
 void d_filter_gaussian_1(float* a, int b, float c, int d, int e) { stm_d_filter_gaussian_1(a, b, c, d, e); }
 void d_filter_bleed_1(unsigned char* a, int b, int c, int d) { stm_d_filter_bleed_1(a, b, c, d); }
 void filter_bleed_1(unsigned char* a, int b, int c, int d) { stm_filter_bleed_1(a, b, c, d); }
+void filter_median(float* a, int b, int c) { stm_filter_median(a, b, c); }
+void d_filter_median(float* a, int b, int c) { stm_d_filter_median(a, b, c); }
 void d_dibr_occl_to_mask(float* a, float* b, unsigned char* c, unsigned char* d, int e, int f) { stm_d_dibr_occl_to_mask(a, b, c, d, e, f); }
 void dibr_occl_to_mask(float* a, float* b, unsigned char* c, unsigned char* d, int e, int f) { stm_dibr_occl_to_mask(a, b, c, d, e, f); }
 void d_dibr_occl(unsigned char* a, unsigned char* b, float* c, float* d, int e, int f) { stm_d_dibr_occl(a, b, c, d, e, f); }

@@ -81,6 +81,43 @@ void launch_bleed(const u8 *in, u8 *out, int radius, int H, int W)
     STM_CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------ 3x3 "median" (d_filter.cu:7-45)
+// Samples by flat index without border handling (a step off the row lands in the neighbouring row; an index
+// outside the buffer -- an out-of-bounds read in the reference -- is clamped), selection sort on the values
+// truncated to int with the truncated values written back by every swap, slot 4 is the result.
+__global__ __launch_bounds__(256) void stm_k_median3(const float *__restrict__ in, float *__restrict__ out, int H, int W)
+{
+    const int tx = blockIdx.x * 256 + threadIdx.x, ty = blockIdx.y;
+    if (tx >= W) return;
+    const long HW = (long)H * W;
+    float v[9];
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+        long q = (long)(tx + n % 3 - 1) + (long)(ty + n / 3 - 1) * W;
+        q = min(max(q, 0l), HW - 1);
+        v[n] = in[q];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        int cur = (int)v[i]; // v_cvt_i32_f32: truncates, saturates, NaN -> 0
+#pragma unroll
+        for (int j = i; j < 9; ++j) {
+            const int comp = (int)v[j];
+            if (comp < cur) {
+                v[j] = (float)cur;
+                v[i] = (float)comp;
+                cur = comp;
+            }
+        }
+    }
+    out[(size_t)ty * W + tx] = v[4];
+}
+void launch_median3(const float *in, float *out, int H, int W)
+{
+    hipLaunchKernelGGL(stm_k_median3, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), in, out, H, W);
+    STM_CHECK_LAUNCH();
+}
+
 __global__ __launch_bounds__(256) void stm_k_occl_to_mask(float *__restrict__ ml, float *__restrict__ mr,
                                                           const u8 *__restrict__ ol, const u8 *__restrict__ orr, size_t HW)
 {

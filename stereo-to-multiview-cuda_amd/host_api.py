@@ -120,6 +120,14 @@ def filter_gaussian_1(img, radius, sigma_spatial):
     return img
 
 
+def filter_median(img):
+    """d_filter.h:11-12."""
+    img = np.array(img, dtype=np.float32, order="C", copy=True)
+    H, W = img.shape
+    lib().stm_filter_median(img.ctypes.data_as(f32p), H, W)
+    return img
+
+
 def filter_bleed_1(img, radius):
     """d_filter.h:26-28."""
     img = np.array(img, dtype=np.uint8, order="C", copy=True)

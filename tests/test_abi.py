@@ -20,7 +20,7 @@ def test_header_declares_the_reference_stage_api():
     names = _declared_c_symbols()
     # one host + one device flavour per reference stage wrapper
     for stage in ["ci_adcensus", "ca_cross", "dc_wta", "dc_hslo", "dr_dcc", "dr_irv", "filter_bilateral_1",
-                  "filter_gaussian_1", "filter_bleed_1", "dibr_occl", "dibr_occl_to_mask", "dibr_dbm", "dibr_dfm",
+                  "filter_gaussian_1", "filter_bleed_1", "filter_median", "dibr_occl", "dibr_occl_to_mask", "dibr_dbm", "dibr_dfm",
                   "mux_multiview", "adcensus_stm"]:
         assert "stm_" + stage in names, stage
         assert "stm_d_" + stage in names, "d_" + stage
@@ -42,7 +42,7 @@ def test_dropin_cxx_names_are_exported(stm):
     txt = open(os.path.join(INC, "stm_dropin.hpp")).read()
     txt = re.sub(r"//.*", "", txt)
     want = sorted(set(re.findall(r"^void\s+([a-z_0-9]+)\s*\(", txt, flags=re.M)))
-    assert len(want) == 28
+    assert len(want) == 30
     out = subprocess.check_output(["nm", "-D", "--defined-only", "-C", stm.LIB_PATH]).decode()
     have = set(re.findall(r" T ([a-z_0-9]+)\(", out))
     assert not [w for w in want if w not in have]

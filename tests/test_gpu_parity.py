@@ -165,6 +165,16 @@ def test_gaussian_and_bleed(api, orc):
         assert np.array_equal(api.filter_bleed_1(b, r), orc.filter_bleed_1(b, r))
 
 
+@pytest.mark.parametrize("H,W", [(1, 1), (2, 3), (45, 70), (33, 300)])
+def test_median(api, orc, H, W):
+    """filter_median (d_filter.h:11-12): int-truncating selection sort, flat-index sampling (no border rule)."""
+    rng = np.random.RandomState(H * 1000 + W)
+    whole = rng.randint(-40, 40, size=(H, W)).astype(np.float32)          # disparity-like: integer valued
+    frac = (rng.random_sample((H, W)) * 60 - 30).astype(np.float32)       # bilateral output: fractional
+    for img in (whole, frac):
+        assert np.array_equal(api.filter_median(img), orc.filter_median(img))
+
+
 @pytest.mark.parametrize("H,W", [(48, 64), (37, 53), (90, 310)])
 def test_dibr_and_mux(api, orc, H, W):
     L, R = rand_pair(H, W, 77)

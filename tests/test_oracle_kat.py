@@ -202,3 +202,34 @@ def test_bud_pair_matches_survey_understanding_check(orc, stm):
     ol, _ = orc.dr_dcc(dl, dr)
     assert 0.13 < (ol > 0).mean() < 0.16
     assert 1.0e6 < al.max() < 1.2e6
+
+
+def test_median_sorts_truncated_values_and_samples_by_flat_index(orc):
+    """d_filter.cu:7-45.  (1) integer-valued interior pixels get the true 3x3 median; (2) the column step at x = 0
+    wraps into the previous row of the flat buffer; (3) the sort compares int-truncated values and swaps write the
+    truncated values back, checked against a literal Python transcription of that rule on a fractional image."""
+    rng = np.random.RandomState(11)
+    a = rng.randint(-20, 20, size=(6, 7)).astype(np.float32)
+    out = orc.filter_median(a)
+    for y in range(1, 5):
+        for x in range(1, 6):
+            assert out[y, x] == np.median(a[y - 1:y + 2, x - 1:x + 2])
+    flat = a.ravel()
+    y, x, W = 3, 0, 7
+    win = [flat[(x + dx) + (y + dy) * W] for dy in (-1, 0, 1) for dx in (-1, 0, 1)]   # dx = -1 -> previous row's end
+    assert out[y, x] == sorted(win)[4]
+
+    f = (rng.random_sample((5, 6)) * 9 - 3).astype(np.float32)
+    HW = f.size
+    want = np.empty_like(f)
+    for y in range(5):
+        for x in range(6):
+            v = [float(f.ravel()[min(max((x + dx) + (y + dy) * 6, 0), HW - 1)]) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+            for i in range(9):
+                cur = int(v[i])
+                for j in range(i, 9):
+                    comp = int(v[j])
+                    if comp < cur:
+                        v[j], v[i], cur = float(cur), float(comp), comp
+            want[y, x] = np.float32(v[4])
+    assert np.array_equal(orc.filter_median(f), want)
