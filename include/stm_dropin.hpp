@@ -98,6 +98,18 @@ void adcensus_stm(unsigned char* img_sbs, float* disp_l, float* disp_r, unsigned
                   int num_views, float angle, int num_disp, int zero_disp,
                   float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
                   int thresh_s, float thresh_h);
+// d_io.h:42-52 (same `float angle` note as adcensus_stm)
+void adcensus_stm_2(unsigned char* img_sbs, float* disp_l, float* disp_r, unsigned char* interlaced,
+                    int num_rows, int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out,
+                    int num_rows_disp, int num_cols_disp, int elem_sz, float disp_scale,
+                    int num_views, float angle, int num_disp, int zero_disp,
+                    float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
+                    int thresh_s, float thresh_h);
+// d_tx_scale.h:19-20 (host pointers, despite the prefix: d_tx_scale.cu:82-127)
+void d_tx_scale(unsigned char* in_data, unsigned char* out_data, int in_rows, int in_cols, int out_rows, int out_cols,
+                int elem_sz);
+// d_filter_gaussian.h:30
+void generateGaussianKernel(float* kernel, int radius, float sigma);
 
 #if defined(STM_BUILD) && defined(__GNUC__)
 #pragma GCC visibility pop

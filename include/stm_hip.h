@@ -209,6 +209,10 @@ void stm_d_adcensus_stm_2(unsigned char *d_img_sbs, float *d_disp_l, float *d_di
 void stm_d_tx_scale(unsigned char *img_in, unsigned char *img_out, int in_rows, int in_cols, int out_rows, int out_cols,
                     int elem_sz);
 
+/* d_filter_gaussian.h:30 (d_filter_gaussian.cu:237-255): the (2r+1)^2 spatial kernel the two big stencils use,
+ * exp(-(x^2+y^2)/(2 s^2)) / (2 pi s^2) with the reference's float/double mix, row-major.  Host-only helper. */
+void stm_generate_gaussian_kernel(float *kernel, int radius, float sigma);
+
 /* ------------------------------------------------- frame sequences */
 /* The reference's video loop (video_io.cpp:144-165) calls adcensus_stm once per decoded frame, serialising upload,
  * compute and download.  A frame stream keeps the same per-frame contract (one side-by-side frame in; disp_l,

@@ -46,6 +46,7 @@ PROTOS = {
     "stm_filter_bleed_1": ([u8p, i, i, i], None),
     "stm_d_filter_bleed_1": ([vp, i, i, i], None),
     "stm_filter_median": ([f32p, i, i], None),
+    "stm_generate_gaussian_kernel": ([f32p, i, f], None),
     "stm_d_filter_median": ([vp, i, i], None),
     "stm_dibr_occl": ([u8p, u8p, f32p, f32p, i, i], None),
     "stm_d_dibr_occl": ([vp, vp, vp, vp, i, i], None),

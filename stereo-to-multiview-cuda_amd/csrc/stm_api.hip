@@ -766,6 +766,12 @@ void stm_d_tx_scale(unsigned char *img_in, unsigned char *img_out, int in_rows, 
     sync();
 }
 
+void stm_generate_gaussian_kernel(float *kernel, int radius, float sigma)
+{
+    if (!args_ok("generate_gaussian_kernel", {{"radius", radius, 0}})) return;
+    gaussian_kernel_2d(kernel, radius, sigma);
+}
+
 void stm_adcensus_stm(unsigned char *img_sbs, float *disp_l, float *disp_r, unsigned char *interlaced, int num_rows,
                       int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out, int elem_sz, int num_views,
                       float angle, int num_disp, int zero_disp, float ad_coeff, float census_coeff, float ucd, float lcd,

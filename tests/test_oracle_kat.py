@@ -233,3 +233,12 @@ def test_median_sorts_truncated_values_and_samples_by_flat_index(orc):
                         v[j], v[i], cur = float(cur), float(comp), comp
             want[y, x] = np.float32(v[4])
     assert np.array_equal(orc.filter_median(f), want)
+
+
+def test_generate_gaussian_kernel_matches_oracle_table(orc, stm):
+    """generateGaussianKernel (d_filter_gaussian.h:30) is a host-only helper of the library: no GPU needed."""
+    import ctypes as C
+    for r, s in [(10, 15.0), (7, 10.0), (0, 1.0)]:
+        k = np.zeros((2 * r + 1) ** 2, np.float32)
+        stm.lib().stm_generate_gaussian_kernel(k.ctypes.data_as(C.POINTER(C.c_float)), r, s)
+        assert np.array_equal(k, orc.gaussian_kernel_2d(r, s).ravel())
