@@ -548,6 +548,45 @@ def test_image_cli_matches_stage_chain(gpu_ready, orc, golden, tmp_path):
     assert np.array_equal(bmp_io.read_bmp(str(out / "view_3.bmp")), views[3])
 
 
+def test_cxx_host_program_against_the_dropin_header(gpu_ready, orc, golden, tmp_path):
+    """examples/stage_chain.cpp uses the reference's own C++ names (stm_dropin.hpp), is built with plain g++ and
+    linked to libstm_hip.so: the header-swap integration of INTEGRATION.md, executed.  Same chain as image_io.cpp."""
+    import subprocess
+    from conftest import ROOT
+    from stm_amd import bmp_io
+    pkg = os.path.join(ROOT, "stereo-to-multiview-cuda_amd")
+    exe = str(tmp_path / "stage_chain")
+    subprocess.check_call(["g++", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "stage_chain.cpp"), "-L", pkg, "-lstm_hip",
+                           "-Wl,-rpath," + pkg, "-o", exe])
+    L, R = golden["L"], golden["R"]
+    H, W, _ = L.shape
+    bmp_io.write_bmp(str(tmp_path / "l.bmp"), L)
+    bmp_io.write_bmp(str(tmp_path / "r.bmp"), R)
+    D, zd, usd, lsd, N = 8, 5, 9, 4, 8
+    subprocess.check_call([exe, str(tmp_path / "l.bmp"), str(tmp_path / "r.bmp"), str(D), str(zd), str(usd), str(lsd), str(N),
+                           str(tmp_path)])
+    cl, cr = orc.ci_adcensus(L, R, 10.0, 30.0, D, zd)
+    xl, al = orc.ca_cross(L, cl, 6.0, 20.0, usd, lsd)
+    xr, ar = orc.ca_cross(R, cr, 6.0, 20.0, usd, lsd)
+    dl, dr = orc.dc_wta(al, zd), orc.dc_wta(ar, zd)
+    assert np.array_equal(np.fromfile(str(tmp_path / "wta_l.f32"), np.float32).reshape(H, W), dl)
+    ol, orr = orc.dr_dcc(dl, dr)
+    dl, ol = orc.dr_irv(dl, ol, xl, 20, 0.4, D, zd, usd, 1, device_flavour=False)
+    dr, orr = orc.dr_irv(dr, orr, xr, 20, 0.4, D, zd, usd, 1, device_flavour=False)
+    dl, dr = orc.filter_bilateral_1(dl, 7, 7.0, 7.0, D), orc.filter_bilateral_1(dr, 7, 7.0, 7.0, D)
+    assert np.array_equal(np.fromfile(str(tmp_path / "disp_l.f32"), np.float32).reshape(H, W), dl)
+    assert np.array_equal(np.fromfile(str(tmp_path / "disp_r.f32"), np.float32).reshape(H, W), dr)
+    occl_l, occl_r = orc.dibr_occl(dl, dr)
+    ml, mr = orc.dibr_occl_to_mask(orc.filter_bleed_1(occl_l, 1), orc.filter_bleed_1(occl_r, 1))
+    views = [R]
+    for v in range(1, N - 1):
+        shift = float(np.float32(1.0 - (1.0 * np.float32(v)) / (np.float32(N) - 1.0)))
+        views.append(orc.dibr_dbm(L, R, dl, dr, ml, mr, shift, 7, 10.0))
+    views.append(L)
+    assert np.array_equal(bmp_io.read_bmp(str(tmp_path / "interlaced.bmp")), orc.mux_multiview(views, 18.43, H, W, 2))
+
+
 def _fuzz_cases(n, seed):
     rng = np.random.RandomState(seed)
     cases = []
