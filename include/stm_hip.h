@@ -21,8 +21,10 @@
  *   cross arms  table of 4 pointers to u8 planes, order UP, DOWN, LEFT, RIGHT
  *   disparity   float [H][W], signed offset (d - zero_disp)
  *
- * Threading: like the reference (single host thread, default stream) the library keeps one cached
- * workspace per device and one current stream per thread; calls that share a device must not overlap in time.
+ * Threading: the reference is single-threaded on the default stream.  Here every host thread has
+ * its own current stream (stm_set_stream) and its own cached workspace per device, so threads may call into the
+ * library concurrently; device-flavour calls of two threads that touch the same buffers need streams ordered by
+ * the caller.  A thread that ends should call stm_release_workspace() first (its slab is not freed for it).
  *
  * Errors: like the reference (cuda_utils.h:12-21) a HIP failure prints a message and
  * calls exit(1); unlike it, kernel launches are checked too.  stm_set_error_mode(1)

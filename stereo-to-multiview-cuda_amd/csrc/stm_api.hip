@@ -3,6 +3,7 @@
 // (SURVEY.md section 8b); each function cites the reference wrapper it replaces.
 #include "stm_common.h"
 #include <initializer_list>
+#include <mutex>
 #include "../../include/stm_hip.h"
 
 #include <map>
@@ -32,6 +33,8 @@ int cur_dev()
 
 const float *dev_table(int kind, int size, float p0, float p1, size_t n, void (*fill)(float *, int, float, float))
 {
+    static std::mutex mu; // tables are shared by all host threads of the process
+    std::lock_guard<std::mutex> lock(mu);
     auto key = std::make_tuple(cur_dev() * 8 + kind, size, p0, p1);
     auto it = g_tables.find(key);
     if (it != g_tables.end()) return it->second.d;

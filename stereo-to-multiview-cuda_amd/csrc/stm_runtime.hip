@@ -31,14 +31,15 @@ static thread_local hipStream_t g_stream = nullptr;
 hipStream_t stream() { return g_stream; }
 
 // --------------------------------------------------------------- workspace
-// one slab per device; grows geometrically, never shrinks until stm_release_workspace
+// one slab per host thread and device (two threads may drive the same GPU on their own streams); grows
+// geometrically, never shrinks until the owning thread calls stm_release_workspace
 struct WsState {
     char *base = nullptr;
     size_t cap = 0;
     size_t off = 0;
     std::vector<void *> retired; // old slabs still possibly referenced by in-flight kernels
 };
-static WsState g_ws[16];
+static thread_local WsState g_ws[16];
 
 static WsState &ws()
 {

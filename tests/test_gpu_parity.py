@@ -587,6 +587,40 @@ def test_cxx_host_program_against_the_dropin_header(gpu_ready, orc, golden, tmp_
     assert np.array_equal(bmp_io.read_bmp(str(tmp_path / "interlaced.bmp")), orc.mux_multiview(views, 18.43, H, W, 2))
 
 
+def test_two_host_threads_share_the_gpu(api, orc, stm):
+    """Every host thread has its own workspace and current stream: two threads running different stage chains at the
+    same time (ctypes drops the GIL during the calls) get the results of the serial runs."""
+    import threading
+    jobs = [(40, 56, 9, 4, 9, 4, 11), (33, 71, 6, 2, 12, 5, 12)]
+    inputs = [rand_pair(H, W, seed) for (H, W, D, zd, usd, lsd, seed) in jobs]
+    results = [None, None]
+
+    def work(i):
+        H, W, D, zd, usd, lsd, _ = jobs[i]
+        L, R = inputs[i]
+        for _ in range(6):
+            cl, cr = api.ci_adcensus(L, R, 10.0, 30.0, D, zd)
+            x, a = api.ca_cross(L, cl, 6.0, 20.0, usd, lsd)
+            d = api.dc_wta(a, zd)
+            d = api.filter_bilateral_1(d, 7, 5.0, 10.0, max(D, 2))
+        results[i] = (cl, x, a, d)
+        stm.lib().stm_release_workspace()
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i, (H, W, D, zd, usd, lsd, _) in enumerate(jobs):
+        L, R = inputs[i]
+        cl, _ = orc.ci_adcensus(L, R, 10.0, 30.0, D, zd)
+        x, a = orc.ca_cross(L, cl, 6.0, 20.0, usd, lsd)
+        d = orc.filter_bilateral_1(orc.dc_wta(a, zd), 7, 5.0, 10.0, max(D, 2))
+        got = results[i]
+        assert got is not None
+        assert np.array_equal(got[0], cl) and np.array_equal(got[1], x) and np.array_equal(got[2], a) and np.array_equal(got[3], d)
+
+
 def _fuzz_cases(n, seed):
     rng = np.random.RandomState(seed)
     cases = []
