@@ -32,7 +32,8 @@
  * Arguments the reference would turn into undefined behaviour are errors of the same kind:
  * a dimension < 1, elem_sz < 3 (three channels of every element are read), num_views < 2
  * for the interlacer (d_mux_multiview.cu:62-66 reads views[1]), an angle whose row period
- * round(num_views / tan(angle) / elem_sz) is 0 (ty % 0, :55), num_cols > 8192 in ca_cross.
+ * round(num_views / tan(angle) / elem_sz) is 0 (ty % 0, :55) or not finite (tan(angle) == 0, :146),
+ * num_cols > 8192 in ca_cross.
  *
  * All file:line citations are relative to the reference repository root.
  */

@@ -167,9 +167,18 @@ void core_mux(const u8 *const *d_views, u8 *d_out, int N, float angle, int Hin, 
               int variant)
 {
     float yi = mux_y_interval(N, angle, elem_sz);
+    // tan(angle) = 0 divides by zero in the reference (d_mux_multiview.cu:146, SURVEY A-Q24); a period beyond the int
+    // range would make the (int) conversion undefined
+    if (!(fabsf(yi) < 1.0e9f)) {
+        fail("mux_multiview: y_interval is not finite (tan(angle) == 0 or angle is not a number)", "angle", __FILE__, __LINE__);
+        return;
+    }
     int ymod = (int)roundf(yi);
-    if (ymod == 0) fail("mux_multiview: round(y_interval) == 0 (angle too steep)", "ymod", __FILE__, __LINE__);
-    launch_mux(d_views, d_out, N, yi, 1.0f / yi, ymod == 0 ? 1 : ymod, Hin, Win, Hout, Wout, elem_sz, variant);
+    if (ymod == 0) {
+        fail("mux_multiview: round(y_interval) == 0 (angle too steep)", "ymod", __FILE__, __LINE__);
+        return;
+    }
+    launch_mux(d_views, d_out, N, yi, 1.0f / yi, ymod, Hin, Win, Hout, Wout, elem_sz, variant);
 }
 
 } // namespace

@@ -424,6 +424,8 @@ def test_error_mode_records_instead_of_exiting(gpu_ready, stm):
         views = np.zeros((2, 4, 4, 3), np.uint8)
         host_api.mux_multiview([views[0], views[1]], 80.0, 4, 4)  # round(N / tan(angle) / 3) == 0: `ty % 0` in d_mux_multiview.cu:55
         assert b"y_interval" in lib.stm_last_error()
+        host_api.mux_multiview([views[0], views[1]], 0.0, 4, 4)     # tan(0): division by zero at :146 (SURVEY A-Q24)
+        assert b"not finite" in lib.stm_last_error()
         host_api.mux_multiview([views[0]], 18.43, 4, 4)             # one view: views[1] is read (:62-66)
         assert b"num_views = 1" in lib.stm_last_error()
         host_api.dc_wta(np.zeros((0, 4, 4), np.float32), 0)         # no hypotheses
