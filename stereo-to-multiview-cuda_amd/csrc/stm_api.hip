@@ -234,7 +234,7 @@ void stm_d_ca_cross(unsigned char *d_img, float **d_cost, float **d_acost, float
                                 {"elem_sz", elem_sz, 3}}))
         return;
     size_t HW = (size_t)num_rows * num_cols;
-    Workspace::begin(HW * 4 + 4096);
+    Workspace::begin(2 * HW * 4 + 8192);
     for (int d = 0; d < num_disp; ++d) h_acost[d] = d_acost_memory + (size_t)d * HW; // d_ca_cross.cu:207-210
     STM_CHECK(hipMemcpyAsync(d_acost, h_acost, sizeof(float *) * num_disp, hipMemcpyHostToDevice, stream()));
     Arms a = arms_from_table(d_cross);
@@ -251,7 +251,7 @@ void stm_ca_cross(unsigned char *img, unsigned char **cross, float **cost, float
                               {"elem_sz", elem_sz, 3}}))
         return;
     size_t HW = (size_t)num_rows * num_cols, V = HW * num_disp;
-    Workspace::begin(2 * V * 4 + HW * elem_sz + 8 * HW + 8192);
+    Workspace::begin(2 * V * 4 + HW * elem_sz + 12 * HW + 16384);
     u8 *dimg = up(img, HW * elem_sz);
     float *c = up_planes(cost, num_disp, HW);
     float *s = Workspace::get<float>(V);

@@ -25,18 +25,21 @@
 namespace stm {
 
 // ------------------------------------------------------------------ cross arms
-// max over B,G,R of |difference| between two packed pixels, from their per-channel masked copies
-// (x & 0xff, x & 0xff00, x & 0xff0000): |a_ch - b_ch| is one v_sad_u8 on operands whose other bytes are zero.
-struct Px3 {
-    uint32_t b, g, r;
-};
-__device__ __forceinline__ Px3 split_bgrx(uint32_t p) { return Px3{p & 0xffu, p & 0xff00u, p & 0xff0000u}; }
-__device__ __forceinline__ int mad_px3(const Px3 &x, const Px3 &y)
+// Colour tests on "wide" pixels: B | G << 10 | R << 20, i.e. three 10-bit fields of which bit 9 is a guard bit.
+// For a threshold t in [-1, 255], maxdiff(c, a) <= t  <=>  for every channel c + t >= a and a + t >= c.  With
+// TG = (512 + t) in every field, the fields of (c + TG) - a and of (a + TG) - c are c_i + 512 + t - a_i and
+// a_i + 512 + t - c_i: always inside [256, 1022], so fields never borrow from or carry into each other, and a
+// field's guard bit is set exactly when its inequality holds.  One add, two subtracts, two ANDs and a compare test
+// all three channels in both directions; the per-channel version took three masks, three v_sad_u8 and a v_max3.
+constexpr uint32_t W10_ONE = 1u | (1u << 10) | (1u << 20);
+constexpr uint32_t W10_GUARD = 512u * W10_ONE;
+
+__global__ __launch_bounds__(256) void stm_k_widen_px(const uint32_t *__restrict__ bgrx, uint32_t *__restrict__ wide, int n)
 {
-    const int d0 = (int)__builtin_amdgcn_sad_u8(x.b, y.b, 0u);
-    const int d1 = (int)__builtin_amdgcn_sad_u8(x.g, y.g, 0u);
-    const int d2 = (int)__builtin_amdgcn_sad_u8(x.r, y.r, 0u);
-    return max(max(d0, d1), d2);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = bgrx[i];
+    wide[i] = (p & 0xffu) | ((p & 0xff00u) << 2) | ((p & 0xff0000u) << 4);
 }
 
 // One arm: walk k = 1..kmax pixels from the anchor (kmax = min(usd, distance to the border): the reference's
@@ -44,66 +47,87 @@ __device__ __forceinline__ int mad_px3(const Px3 &x, const Px3 &y)
 // test (SURVEY A-Q9, :47-64): near tier (k <= lsd) stops when anchor-vs-current or previous-vs-current exceeds
 // lcd, far tier when anchor-vs-current exceeds ucd.  `(float)int > float` is evaluated as int > floor(float),
 // which is the same predicate for every integer left-hand side.
-__device__ __forceinline__ int one_arm(const uint32_t *__restrict__ p, int stride, int kmax, int lsd, int t_far, int t_near,
-                                       const Px3 &anchor)
+//   tg_near / tg_far = (512 + threshold) in every field, anchor = the wide anchor pixel.
+__device__ __forceinline__ int one_arm(const uint32_t *__restrict__ p, int stride, int kmax, int lsd, uint32_t tg_far,
+                                       uint32_t tg_near, uint32_t anchor)
 {
-    Px3 prev = anchor;
     int arm = 0;
-    for (int k = 1; k <= kmax; ++k) {
+    const int knear = min(kmax, lsd);
+    const uint32_t anchor_n = anchor + tg_near;
+    uint32_t prev = anchor, prev_t = anchor_n; // previous pixel and previous pixel + TG
+    int k = 1;
+    for (; k <= knear; ++k) {
         p += stride;
-        const Px3 c = split_bgrx(*p);
+        const uint32_t c = *p;
         arm = k;
-        const int ac = mad_px3(c, anchor);
-        if (k > lsd) {
-            if (ac > t_far) break;
-        } else {
-            if (ac > t_near || mad_px3(c, prev) > t_near) break;
-            prev = c;
-        }
+        const uint32_t c_t = c + tg_near;
+        const uint32_t ok = (c_t - anchor) & (anchor_n - c) & (c_t - prev) & (prev_t - c) & W10_GUARD;
+        if (ok != W10_GUARD) return arm;
+        prev = c;
+        prev_t = c_t;
+    }
+    const uint32_t far_lo = tg_far - anchor, far_hi = anchor + tg_far;
+    for (; k <= kmax; ++k) {
+        p += stride;
+        const uint32_t c = *p;
+        arm = k;
+        const uint32_t ok = (c + far_lo) & (far_hi - c) & W10_GUARD;
+        if (ok != W10_GUARD) return arm;
     }
     return arm;
 }
 
 struct ArmsArgs {
-    const uint32_t *img[2];
+    const uint32_t *img[2]; // wide pixels
     u8 *up[2], *down[2], *left[2], *right[2];
 };
 
-__global__ __launch_bounds__(256) void stm_k_cross_arms(ArmsArgs a, int t_far, int t_near, int usd, int lsd, int H, int W)
+__global__ __launch_bounds__(256) void stm_k_cross_arms(ArmsArgs a, uint32_t tg_far, uint32_t tg_near, int usd, int lsd, int H, int W)
 {
     const int v = blockIdx.z;
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
     const int p = y * W + x;
     const uint32_t *__restrict__ img = a.img[v] + p;
-    const Px3 anchor = split_bgrx(*img);
-    a.up[v][p] = (u8)one_arm(img, -W, min(usd, y), lsd, t_far, t_near, anchor);
-    a.down[v][p] = (u8)one_arm(img, W, min(usd, H - 1 - y), lsd, t_far, t_near, anchor);
-    a.left[v][p] = (u8)one_arm(img, -1, min(usd, x), lsd, t_far, t_near, anchor);
-    a.right[v][p] = (u8)one_arm(img, 1, min(usd, W - 1 - x), lsd, t_far, t_near, anchor);
+    const uint32_t anchor = *img;
+    a.up[v][p] = (u8)one_arm(img, -W, min(usd, y), lsd, tg_far, tg_near, anchor);
+    a.down[v][p] = (u8)one_arm(img, W, min(usd, H - 1 - y), lsd, tg_far, tg_near, anchor);
+    a.left[v][p] = (u8)one_arm(img, -1, min(usd, x), lsd, tg_far, tg_near, anchor);
+    a.right[v][p] = (u8)one_arm(img, 1, min(usd, W - 1 - x), lsd, tg_far, tg_near, anchor);
 }
 
-static int int_threshold(float t)
+// threshold as the integer t with (int diff > threshold) <=> (diff > t), clamped to [-1, 255], times the field pattern
+static uint32_t wide_threshold(float t)
 {
-    if (t != t) return 1 << 30;    // NaN: '>' is never true
-    if (t >= 256.f) return 1 << 30; // above any 8-bit difference
-    if (t < 0.f) return -1;         // every difference (>= 0) exceeds it
-    return (int)floorf(t);
+    int ti;
+    if (t != t) ti = 255;         // NaN: '>' is never true
+    else if (t >= 255.f) ti = 255; // no 8-bit difference exceeds it
+    else if (t < 0.f) ti = -1;     // every difference (>= 0) exceeds it
+    else ti = (int)floorf(t);
+    return (uint32_t)(512 + ti) * W10_ONE;
 }
 
-// nviews = 1 or 2: both views of a frame share the launch
+// nviews = 1 or 2: both views of a frame share the launch.  packed[] = BGRX planes (launch_pack_bgrx).
 void launch_cross_arms2(int nviews, const uint32_t *const *packed, u8 *const *up, u8 *const *down, u8 *const *left,
                         u8 *const *right, float ucd, float lcd, int usd, int lsd, int H, int W)
 {
     ArmsArgs a;
+    const int n = H * W;
+    ProfScope p("cross_arms");
+    const uint32_t *wide[2];
+    for (int v = 0; v < nviews; ++v) {
+        uint32_t *w = Workspace::get<uint32_t>((size_t)n);
+        hipLaunchKernelGGL(stm_k_widen_px, dim3(cdiv(n, 256)), dim3(256), 0, stream(), packed[v], w, n);
+        STM_CHECK_LAUNCH();
+        wide[v] = w;
+    }
     for (int v = 0; v < 2; ++v) {
         const int s = v < nviews ? v : 0;
-        a.img[v] = packed[s]; a.up[v] = up[s]; a.down[v] = down[s]; a.left[v] = left[s]; a.right[v] = right[s];
+        a.img[v] = wide[s]; a.up[v] = up[s]; a.down[v] = down[s]; a.left[v] = left[s]; a.right[v] = right[s];
     }
     if (usd > 255) usd = 255; // arms are stored as u8 (reference T2)
-    ProfScope p("cross_arms");
-    hipLaunchKernelGGL(stm_k_cross_arms, dim3(cdiv(W, 256), H, nviews), dim3(256), 0, stream(), a, int_threshold(ucd),
-                       int_threshold(lcd), usd, lsd, H, W);
+    hipLaunchKernelGGL(stm_k_cross_arms, dim3(cdiv(W, 256), H, nviews), dim3(256), 0, stream(), a, wide_threshold(ucd),
+                       wide_threshold(lcd), usd, lsd, H, W);
     STM_CHECK_LAUNCH();
 }
 
