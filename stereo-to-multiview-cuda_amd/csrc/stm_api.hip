@@ -347,7 +347,7 @@ void stm_d_dr_irv(float *d_disp, unsigned char *d_outliers, unsigned char **d_cr
 {
     if (!args_ok("d_dr_irv", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}, {"num_disp", num_disp, 1}})) return;
     size_t HW = (size_t)num_rows * num_cols;
-    Workspace::begin(20 * HW + 8192);
+    Workspace::begin(30 * HW + 65536);
     Arms a = arms_from_table(d_cross);
     float *dv[1] = {d_disp};
     u8 *ov[1] = {d_outliers};
@@ -359,7 +359,7 @@ void stm_dr_irv(float *disp, unsigned char *outliers, unsigned char **cross, int
 {
     if (!args_ok("dr_irv", {{"num_rows", num_rows, 1}, {"num_cols", num_cols, 1}, {"num_disp", num_disp, 1}})) return;
     size_t HW = (size_t)num_rows * num_cols;
-    Workspace::begin(28 * HW + 16384);
+    Workspace::begin(40 * HW + 65536);
     float *d = up(disp, HW);
     u8 *o = up(outliers, HW);
     Arms a{up(cross[0], HW), up(cross[1], HW), up(cross[2], HW), up(cross[3], HW)};
@@ -687,7 +687,7 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
     const int H = num_rows, W = num_cols, N = num_views;
     const size_t HW = (size_t)H * W, IMG = HW * elem_sz;
     const size_t V = HW * (size_t)((num_disp + 3) / 4) * 4;
-    Workspace::begin(((stages & 0x100) ? 13 : 3) * V * 4 + (size_t)(N + 2) * IMG + 112 * HW + (1u << 20));
+    Workspace::begin(((stages & 0x100) ? 13 : 3) * V * 4 + (size_t)(N + 2) * IMG + 128 * HW + (1u << 20));
     u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
     launch_demux_sbs(img_l, img_r, d_img_sbs, H, num_cols_sbs, W, elem_sz);
     Arms al, ar;

@@ -61,10 +61,10 @@ void launch_dcc(u8 *out_l, u8 *out_r, const float *disp_l, const float *disp_r, 
 // ------------------------------------------------------------------ iterative region voting
 // Outliers are few (2 % of a synthetic frame, ~15 % of a real one, fewer every iteration) but each one
 // walks a cross region of ~600 pixels, so a thread per pixel leaves most lanes idle and a thread per
-// outlier leaves most of the CHIP idle.  Here: (1) a compaction kernel lists the outlier pixels;
-// (2) a persistent grid of waves pulls outliers off the list, one WAVE per outlier: each half-wave takes
-// one row of the cross region (32 pixels per step, coalesced), equal bins are merged with ballots and
-// counted in a per-wave LDS histogram, and the winner is a wave-wide max over (count, -bin).
+// outlier leaves most of the CHIP idle.  Here: (1) a compaction kernel lists the outlier pixels once;
+// (2) per iteration a persistent grid of waves walks the list, one WAVE per outlier: one row of the cross
+// region per step (lanes = pixels, coalesced), votes counted in a per-wave LDS histogram, the winner is a
+// wave-wide max over (count, -bin), and the same wave applies the accept test.
 // Every outlier's result is independent of the list order, so the atomic compaction is deterministic
 // where it matters.  Histogram: max(D,65) bins (the reference's int[65] overflows for D > 65, A-Q17 ii).
 // Both views of a frame go through every IRV launch together (blockIdx.y = view).
@@ -72,12 +72,16 @@ struct IrvArgs {
     float *disp[2];
     u8 *outl[2];
     const u8 *aU[2], *aD[2], *aL[2], *aR[2];
-    int *max_disp[2], *reliable[2];
-    uint32_t *list_a[2], *list_b[2]; // ping-pong outlier lists
-    int *counts[2];                  // counts[v][k] = length of the list that iteration k votes on
-    u8 *dirty[2];                    // dirty[v][it][tile]: a pixel of the 64x64 tile was accepted in iteration it
-    int16_t *code[2];                // per pixel: histogram bin of a reliable pixel, -1 = outlier (no vote), -2 = reliable, bin out of range
+    uint32_t *list[2]; // outlier pixels in raster order; entries are retired in place (IV_ACCEPTED, IV_DEAD)
+    int *counts[2];    // counts[v][0] = length of the list
+    u8 *dirty[2];      // dirty[v][it][tile]: a pixel of the 64x64 tile was accepted in iteration it
+    // per pixel: histogram bin of a reliable pixel, -1 = outlier (no vote), -2 = reliable with the bin out of range.
+    // Two planes: iteration `it` reads plane it & 1 (the state all its votes see, as the reference's separate vote
+    // and apply kernels guarantee) and writes the pixels it accepts into the other plane.
+    int16_t *code[2][2];
 };
+constexpr uint32_t IV_ACCEPTED = 0x80000000u; // list entry: pixel accepted in the previous iteration
+constexpr uint32_t IV_DEAD = 0xFFFFFFFFu;     // list entry: nothing left to do
 
 // vote code of one pixel: (int)disp + zero_disp is the histogram bin (d_dr_irv.cu:200-201)
 __device__ __forceinline__ int16_t irv_code(u8 outl, float disp, int zd, int nb)
@@ -92,18 +96,27 @@ __global__ __launch_bounds__(256) void stm_k_irv_compact(IrvArgs a, uint32_t HW,
 {
     const int v = blockIdx.y;
     const u8 *__restrict__ outl = a.outl[v];
-    {   // the same pass packs (outlier flag, disparity) into the 16-bit vote code the vote kernel reads
-        const uint32_t p0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
-        for (uint32_t j = 0; j < 4 && p0 + j < HW; ++j) a.code[v][p0 + j] = irv_code(outl[p0 + j], a.disp[v][p0 + j], zd, nb);
-    }
-    uint32_t *__restrict__ list = a.list_a[v];
+    const float *__restrict__ disp = a.disp[v];
+    uint32_t *__restrict__ list = a.list[v];
     const uint32_t p = (blockIdx.x * 256u + threadIdx.x) * 4u;
     const int lane = threadIdx.x & 63;
     uint32_t w = 0;
-    if (p < HW) {
-        if (p + 4 <= HW && (((uintptr_t)outl) & 3) == 0) w = *(const uint32_t *)(outl + p);
-        else
-            for (uint32_t j = 0; j < 4 && p + j < HW; ++j) w |= (uint32_t)outl[p + j] << (8 * j);
+    // the same pass packs (outlier flag, disparity) into the 16-bit vote code the vote kernel reads:
+    // one dword of flags + one float4 of disparities in, four codes (8 bytes) out per thread
+    if (p + 4 <= HW && ((((uintptr_t)outl) & 3) | (((uintptr_t)disp) & 15)) == 0) {
+        w = *(const uint32_t *)(outl + p);
+        const float4 d = *(const float4 *)(disp + p);
+        const uint32_t c0 = (uint16_t)irv_code((u8)(w & 0xff), d.x, zd, nb), c1 = (uint16_t)irv_code((u8)((w >> 8) & 0xff), d.y, zd, nb);
+        const uint32_t c2 = (uint16_t)irv_code((u8)((w >> 16) & 0xff), d.z, zd, nb), c3 = (uint16_t)irv_code((u8)(w >> 24), d.w, zd, nb);
+        const uint2 cc = make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
+        *(uint2 *)(a.code[v][0] + p) = cc; // the code planes are workspace memory: aligned
+        *(uint2 *)(a.code[v][1] + p) = cc;
+    } else if (p < HW) {
+        for (uint32_t j = 0; j < 4 && p + j < HW; ++j) {
+            const u8 o = outl[p + j];
+            w |= (uint32_t)o << (8 * j);
+            a.code[v][0][p + j] = a.code[v][1][p + j] = irv_code(o, disp[p + j], zd, nb);
+        }
     }
     int c = ((w & 0xff) != 0) + ((w & 0xff00) != 0) + ((w & 0xff0000) != 0) + ((w & 0xff000000u) != 0);
     if (__ballot(c != 0) == 0) return; // wave-uniform
@@ -136,32 +149,52 @@ __device__ __forceinline__ void irv_tally(int code, uint32_t *hist, int &total)
     if (code >= 0) atomicAdd(&hist[code], 1u);
 }
 
-// iteration `it` (0-based) votes on list (it even ? list_a : list_b) of length counts[v][it].
+// Iteration `it` (0-based): vote (dr_irv_pre_kernel, d_dr_irv.cu:134-220) and apply (dr_irv_kernel_3, :17-43) for
+// every live pixel of the outlier list.
 // One wave per outlier, one region row per wave step (lanes = pixels of the row segment, coalesced), IV_U rows
 // in flight together.  The kernel is instruction-issue bound (8 waves per SIMD hide all latency), so everything
 // that is uniform over the wave is kept in SGPRs: row arms are fetched once into lanes and broadcast with
 // v_readlane, row offsets are 32-bit scalar arithmetic.
+// Apply in the same kernel: the reference votes for ALL outliers on one state and only then updates it.  Here the
+// votes read code plane `it & 1`, which nothing writes during this launch; an accepted pixel is written to the
+// disparity / outlier maps (no vote reads them) and to the OTHER code plane, and its list entry is tagged
+// IV_ACCEPTED; the next launch, whose write plane still lacks that pixel, copies it over and retires the entry.
+// The list is never re-compacted: it stays in raster order, so waves that run together work on neighbouring
+// outliers whose cross regions overlap in cache (re-listing through atomics scrambled that and cost 40 %).
 // Pruning: an outlier whose cross region saw no accepted pixel in the previous iteration would repeat its
-// previous vote exactly (the vote is a pure function of the region), so it is skipped; `dirty` holds one byte
-// per 64x64 tile and iteration, set by the apply kernel.
+// previous vote exactly (the vote is a pure function of the region) and be rejected again, so it is skipped;
+// `dirty` holds one byte per 64x64 tile and iteration.
 constexpr int IV_TILE = 64;
-__global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int it, int H, int W, int nb, int zd, int usd,
-                                                                int tiles_x, int tiles_y)
+__global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int it, int thresh_s, float thresh_h, int H, int W,
+                                                                int nb, int zd, int usd, int tiles_x, int tiles_y)
 {
-    extern __shared__ uint32_t hist_all[]; // [IV_WAVES][nb]
+    extern __shared__ uint32_t irv_lds[]; // per wave: hist[nb]
     const int v = blockIdx.y;
-    const float *__restrict__ disp = a.disp[v];
-    const int16_t *__restrict__ code_pl = a.code[v];
+    float *__restrict__ disp = a.disp[v];
+    const int16_t *__restrict__ code_pl = a.code[v][it & 1];
+    int16_t *__restrict__ code_nx = a.code[v][(it & 1) ^ 1];
     const u8 *__restrict__ aL = a.aL[v], *__restrict__ aR = a.aR[v];
-    const uint32_t *__restrict__ list = (it & 1) ? a.list_b[v] : a.list_a[v];
+    uint32_t *__restrict__ list = a.list[v];
     const u8 *__restrict__ dirty = it > 0 ? a.dirty[v] + (size_t)(it - 1) * tiles_x * tiles_y : nullptr;
+    u8 *__restrict__ dirty_out = a.dirty[v] + (size_t)it * tiles_x * tiles_y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t *hist = hist_all + wave * nb;
-    const int n = a.counts[v][it];
+    uint32_t *hist = irv_lds + wave * nb;
+    const int n = a.counts[v][0];
     for (int i = blockIdx.x * IV_WAVES + wave; i < n; i += gridDim.x * IV_WAVES) {
-        const int p = __builtin_amdgcn_readfirstlane((int)list[i]);
+        const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[i]);
+        if (entry == IV_DEAD) continue;
+        if (entry & IV_ACCEPTED) { // accepted by the previous launch: bring this launch's write plane up to date
+            if (lane == 0) {
+                const uint32_t q = entry & ~IV_ACCEPTED;
+                code_nx[q] = code_pl[q];
+                list[i] = IV_DEAD;
+            }
+            continue;
+        }
+        const int p = (int)entry;
         const int gy = p / W, gx = p - gy * W;
         int cu = a.aU[v][p], cd = a.aD[v][p];
+        const float own = disp[p]; // needed only for the default vote at the very end: issued here so its latency is hidden
         if (cu > usd) cu = usd;   // d_dr_irv.cu:179-180
         cu = min(cu, gy);         // arms built by ca_cross never leave the image; these two clamps only keep a
         cd = min(cd, H - 1 - gy); // caller who passes inconsistent arms from reading outside the planes
@@ -173,7 +206,7 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
             const int nx = tx1 - tx0 + 1, nt = nx * (ty1 - ty0 + 1);
             int d = nt > 64; // more tiles than lanes (usd > 95): do not prune
             if (lane < nt) d = dirty[(ty0 + lane / nx) * tiles_x + tx0 + lane % nx];
-            if (__ballot(d != 0) == 0) continue; // same region contents as last time -> same vote (already stored)
+            if (__ballot(d != 0) == 0) continue; // same region contents as last time -> same vote -> rejected again
         }
         for (int b = lane; b < nb; b += 64) hist[b] = 0;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -182,14 +215,14 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
         const int y_top = gy - cu;
         int total = 0;
         for (int jb = 0; jb < nrows; jb += 128) { // 128 rows per outer step covers every usd <= 63 in one go
-            // horizontal arms of the region's rows, fetched once and packed into ONE register per lane:
-            // bits 0-15 = row jb+lane, bits 16-31 = row jb+64+lane, each (armL | (armL+armR+1) << 8 ... as 8+9 bits)
-            uint32_t packed = 0; // per row: armL in 7 bits is not enough for usd <= 255, so: low byte armL, next 9 bits width
+            // horizontal arms of the region's rows, fetched once and packed into one register per 64 rows:
+            // armL in the low byte, segment width armL + armR + 1 (<= 511) above it
+            uint32_t packed = 0;
             uint32_t packed_hi = 0;
             if (jb + lane < nrows) {
                 const int q = (y_top + jb + lane) * W + gx;
                 const uint32_t cl = aL[q];
-                packed = cl | ((cl + (uint32_t)aR[q] + 1u) << 8); // armL | width << 8  (width <= 511)
+                packed = cl | ((cl + (uint32_t)aR[q] + 1u) << 8);
             }
             if (jb + 64 + lane < nrows) {
                 const int q = (y_top + jb + 64 + lane) * W + gx;
@@ -198,7 +231,7 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
             }
             const int jend = min(nrows - jb, 128);
             for (int j0 = 0; j0 < jend; j0 += IV_U) {
-                int cd[IV_U], wd[IV_U], base[IV_U];
+                int cdv[IV_U], wd[IV_U], base[IV_U];
                 int wmax = 0;
 #pragma unroll
                 for (int u = 0; u < IV_U; ++u) { // first 64 pixels of IV_U rows: all loads issued before any is consumed
@@ -212,11 +245,11 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
                     wd[u] = w;
                     wmax = max(wmax, w);
                     base[u] = (y_top + jb + j) * W + xs;
-                    cd[u] = -1; // -1: no vote (outside the row segment, or an outlier itself)
-                    if (lane < w) cd[u] = code_pl[base[u] + lane];
+                    cdv[u] = -1; // -1: no vote (outside the row segment, or an outlier itself)
+                    if (lane < w) cdv[u] = code_pl[base[u] + lane];
                 }
 #pragma unroll
-                for (int u = 0; u < IV_U; ++u) irv_tally(cd[u], hist, total);
+                for (int u = 0; u < IV_U; ++u) irv_tally(cdv[u], hist, total);
                 if (wmax > 64) { // segments wider than 64 pixels (arm sum >= 64): rare
 #pragma unroll
                     for (int u = 0; u < IV_U; ++u) {
@@ -242,39 +275,21 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
             uint32_t other = (uint32_t)__shfl_xor((int)key, o2);
             if (other > key) key = other;
         }
-        if (lane == 0) {
-            int max_d = (int)disp[p]; // default: own disparity (d_dr_irv.cu:182)
-            if (key != 0) max_d = (0xFFFF - (int)(key & 0xFFFF)) - zd;
-            a.max_disp[v][p] = max_d;
-            a.reliable[v][p] = total;
-        }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// dr_irv_kernel_3 (d_dr_irv.cu:17-43) over the outlier list only (it touches nothing else), fused with the
-// construction of the next iteration's list: pixels that stay outliers are appended to the other list.
-__global__ __launch_bounds__(256) void stm_k_irv_apply(IrvArgs a, int it, int thresh_s, float thresh_h, int zd, int nb, int W,
-                                                       int tiles_x, int tiles_y)
-{
-    const int v = blockIdx.y;
-    const uint32_t *__restrict__ list = (it & 1) ? a.list_b[v] : a.list_a[v];
-    uint32_t *__restrict__ next = (it & 1) ? a.list_a[v] : a.list_b[v];
-    const int n = a.counts[v][it];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint32_t p = list[i];
-        const int tr = a.reliable[v][p], md = a.max_disp[v][p];
-        // ratio uses the winning BIN INDEX, not its count (d_dr_irv.cu:36, SURVEY A-Q17 iv)
-        if (tr > thresh_s && (float)(md + zd) / (float)tr > thresh_h) {
-            a.outl[v][p] = 0;
-            a.reliable[v][p] = tr + 1;
-            a.disp[v][p] = (float)md;
-            a.code[v][p] = irv_code(0, (float)md, zd, nb);
-            const int gy = (int)(p / (uint32_t)W), gx = (int)(p - (uint32_t)gy * (uint32_t)W);
-            a.dirty[v][(size_t)it * tiles_x * tiles_y + (gy / IV_TILE) * tiles_x + gx / IV_TILE] = 1; // same value from every writer
-        } else {
-            next[atomicAdd(&a.counts[v][it + 1], 1)] = p; // wave-aggregated by the compiler
+        key = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+        int max_d = (int)own; // default: own disparity (d_dr_irv.cu:182)
+        if (key != 0) max_d = (0xFFFF - (int)(key & 0xFFFF)) - zd;
+        // apply (d_dr_irv.cu:32-41): the ratio uses the winning BIN INDEX, not its count (:36, SURVEY A-Q17 iv)
+        if (total > thresh_s && (float)(max_d + zd) / (float)total > thresh_h) {
+            const int16_t nc = irv_code(0, (float)max_d, zd, nb);
+            if (lane == 0) {
+                a.outl[v][p] = 0;
+                disp[p] = (float)max_d;
+                code_nx[p] = nc;
+                dirty_out[(gy / IV_TILE) * tiles_x + gx / IV_TILE] = 1; // same value from every writer
+                list[i] = (uint32_t)p | IV_ACCEPTED;
+            }
         }
     }
 }
@@ -291,34 +306,34 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
     IrvArgs a;
     const int tiles_x = cdiv(W, IV_TILE), tiles_y = cdiv(H, IV_TILE);
     const size_t dirty_sz = (size_t)(rounds + 1) * tiles_x * tiles_y;
-    int *counts = Workspace::get<int>(2 * (size_t)(rounds + 2) + (2 * dirty_sz + 3) / 4); // counters, then dirty bytes: one memset
+    const size_t ncount = 4; // per view: list length
+    int *counts = Workspace::get<int>(ncount + (2 * dirty_sz + 3) / 4); // counters, then dirty bytes: one memset
     for (int v = 0; v < 2; ++v) {
         const int s = v < nviews ? v : 0;
         a.disp[v] = disp[s]; a.outl[v] = outl[s];
         a.aU[v] = up[s]; a.aD[v] = down[s]; a.aL[v] = left[s]; a.aR[v] = right[s];
-        a.counts[v] = counts + (size_t)v * (rounds + 2);
-        a.dirty[v] = (u8 *)(counts + 2 * (size_t)(rounds + 2)) + (size_t)v * dirty_sz;
+        a.counts[v] = counts + 2 * v;
+        a.dirty[v] = (u8 *)(counts + ncount) + (size_t)v * dirty_sz;
     }
     for (int v = 0; v < nviews; ++v) {
-        a.max_disp[v] = Workspace::get<int>(HW);
-        a.reliable[v] = Workspace::get<int>(HW);
-        a.list_a[v] = Workspace::get<uint32_t>(HW);
-        a.list_b[v] = Workspace::get<uint32_t>(HW);
-        a.code[v] = Workspace::get<int16_t>(HW);
+        a.list[v] = Workspace::get<uint32_t>(HW);
+        a.code[v][0] = Workspace::get<int16_t>(HW);
+        a.code[v][1] = Workspace::get<int16_t>(HW);
     }
-    if (nviews == 1) { a.max_disp[1] = a.max_disp[0]; a.reliable[1] = a.reliable[0]; a.list_a[1] = a.list_a[0]; a.list_b[1] = a.list_b[0]; a.code[1] = a.code[0]; }
+    if (nviews == 1) { a.list[1] = a.list[0]; a.code[1][0] = a.code[0][0]; a.code[1][1] = a.code[0][1]; }
     if (rounds == 0) return; // nothing observable happens (a host-flavour vote without an apply only fills scratch)
+    if (HW >= IV_ACCEPTED) {
+        fail("dr_irv: more than 2^31 - 1 pixels", "num_rows * num_cols", __FILE__, __LINE__);
+        return;
+    }
     ProfScope p("irv");
-    STM_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * 2 * (size_t)(rounds + 2) + 2 * dirty_sz, stream()));
+    STM_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * ncount + 2 * dirty_sz, stream()));
     hipLaunchKernelGGL(stm_k_irv_compact, dim3((unsigned)((HW + 1023) / 1024), nviews), dim3(256), 0, stream(), a, (uint32_t)HW, zd, nb);
     STM_CHECK_LAUNCH();
     const size_t smem = (size_t)nb * IV_WAVES * 4;
     for (int it = 0; it < rounds; ++it) {
-        hipLaunchKernelGGL(stm_k_irv_vote, dim3(IV_BLOCKS, nviews), dim3(64 * IV_WAVES), smem, stream(), a, it, H, W, nb, zd, usd,
-                           tiles_x, tiles_y);
-        STM_CHECK_LAUNCH();
-        hipLaunchKernelGGL(stm_k_irv_apply, dim3(256, nviews), dim3(256), 0, stream(), a, it, thresh_s, thresh_h, zd, nb, W, tiles_x,
-                           tiles_y);
+        hipLaunchKernelGGL(stm_k_irv_vote, dim3(IV_BLOCKS, nviews), dim3(64 * IV_WAVES), smem, stream(), a, it, thresh_s, thresh_h, H,
+                           W, nb, zd, usd, tiles_x, tiles_y);
         STM_CHECK_LAUNCH();
     }
 }
