@@ -660,10 +660,7 @@ void frame_render(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, u8 *d_
 
     u8 *views_mem = Workspace::get<u8>((size_t)N * IMG);
     // views[0] = right image, views[N-1] = left image (d_io.cu:182-183)
-    for (int v = 1; v < N - 1; ++v) {
-        float shift = (float)(1.0 - ((1.0 * (double)(float)v) / ((double)(float)N - 1.0))); // :189
-        launch_view_synth(views_mem + (size_t)v * IMG, img_l, img_r, d_disp_l, d_disp_r, mask_l, mask_r, blend, shift, H, W, elem_sz);
-    }
+    launch_view_synth_all(views_mem, IMG, N, img_l, img_r, d_disp_l, d_disp_r, mask_l, mask_r, blend, H, W, elem_sz); // :186-201
     // view table built on the device (no host memory involved, so nothing to keep alive or synchronise)
     u8 **dv = Workspace::get<u8 *>(N);
     launch_view_table(dv, img_r, img_l, views_mem, IMG, N);

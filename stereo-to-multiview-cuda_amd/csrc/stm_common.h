@@ -119,6 +119,9 @@ void launch_median3(const float *in, float *out, int H, int W);
 void launch_occl_to_mask(float *mask_l, float *mask_r, const u8 *occl_l, const u8 *occl_r, int H, int W);
 void launch_view_synth(u8 *out, const u8 *img_l, const u8 *img_r, const float *disp_l, const float *disp_r,
                        const float *mask_l, const float *mask_r, const float *blend, float shift, int H, int W, int elem_sz);
+void launch_view_synth_all(u8 *views, size_t view_stride, int N, const u8 *img_l, const u8 *img_r, const float *disp_l,
+                           const float *disp_r, const float *mask_l, const float *mask_r, const float *blend, int H, int W,
+                           int elem_sz);
 void launch_fwarp(u8 *out, const u8 *img, const float *disp, float shift, unsigned long long *keys, int H, int W, int elem_sz);
 void launch_scale_bilinear(const u8 *in, u8 *out, int in_rows, int in_cols, int out_rows, int out_cols, int elem_sz);
 void launch_disp_scale(float *out, const float *in, int out_rows, int out_cols, int in_rows, int in_cols, float disp_scale);

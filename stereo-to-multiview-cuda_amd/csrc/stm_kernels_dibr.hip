@@ -177,6 +177,56 @@ void launch_view_synth(u8 *out, const u8 *img_l, const u8 *img_r, const float *d
     STM_CHECK_LAUNCH();
 }
 
+// All N-2 synthesised views of a frame in one launch (d_io.cu:186-201 loops over d_dibr_dbm): a thread owns one
+// pixel, reads its two disparities, two masks and blend weight once and produces that pixel of every view v = 1..N-2
+// with shift = 1 - v / (N - 1) evaluated as the reference does (:189, in double, narrowed).
+__global__ __launch_bounds__(256) void stm_k_view_synth_all(u8 *__restrict__ views, size_t view_stride, int N,
+                                                            const u8 *__restrict__ img_l, const u8 *__restrict__ img_r,
+                                                            const float *__restrict__ disp_l, const float *__restrict__ disp_r,
+                                                            const float *__restrict__ mask_l, const float *__restrict__ mask_r,
+                                                            const float *__restrict__ blend, int H, int W, int elem_sz)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const size_t row = (size_t)y * W, p = row + x;
+    const float wmax = (float)(W - 1);
+    const float dr = disp_r[p], dl = disp_l[p];
+    const float vmr = mask_r[p], vml = mask_l[p], m = blend[p];
+    const float one_m = 1.0f - m;
+    for (int v = 1; v < N - 1; ++v) {
+        const float shift = (float)(1.0 - ((1.0 * (double)(float)v) / ((double)(float)N - 1.0)));
+        const float shift_l = -shift;                       // d_dibr_bwarp.cu:56
+        const float shift_r = (float)(1.0 - (double)shift); // :57
+        float sd = dr * shift_l;
+        float fx = (float)x + sd;
+        const int sxl = (int)fminf(fmaxf(fx, 0.0f), wmax);
+        sd = dl * shift_r;
+        fx = (float)x + sd;
+        const int sxr = (int)fminf(fmaxf(fx, 0.0f), wmax);
+        const u8 *sl = img_l + (row + sxl) * elem_sz, *sr = img_r + (row + sxr) * elem_sz;
+        u8 *o = views + (size_t)v * view_stride + p * elem_sz;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const u8 a = (u8)((float)sl[c] * vmr);
+            const u8 b = (u8)((float)sr[c] * vml);
+            const float cb = one_m * (float)a;
+            const float ca = m * (float)b;
+            o[c] = (u8)((u8)cb + (u8)ca);
+        }
+    }
+}
+// views = base of N view slots of view_stride bytes; slots 1..N-2 are written
+void launch_view_synth_all(u8 *views, size_t view_stride, int N, const u8 *img_l, const u8 *img_r, const float *disp_l,
+                           const float *disp_r, const float *mask_l, const float *mask_r, const float *blend, int H, int W,
+                           int elem_sz)
+{
+    if (N < 3) return;
+    ProfScope p("view_synth");
+    hipLaunchKernelGGL(stm_k_view_synth_all, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), views, view_stride, N, img_l, img_r,
+                       disp_l, disp_r, mask_l, mask_r, blend, H, W, elem_sz);
+    STM_CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------ forward warp (deterministic)
 // The reference scatter is a data race (SURVEY A-Q23).  Rule here: of all sources landing on one target
 // the LARGEST source x wins, which is what a serial ascending-x loop produces.  Pass 1 resolves the
