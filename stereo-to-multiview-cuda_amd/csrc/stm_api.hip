@@ -613,6 +613,8 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
         u8 *u[2] = {al.up, ar.up}, *d[2] = {al.down, ar.down}, *l[2] = {al.left, ar.left}, *r[2] = {al.right, ar.right};
         launch_cross_arms2(2, pk, u, d, l, r, ucd, lcd, usd, lsd, H, W);
     }
+    // with refinement the raw WTA maps live in scratch and the bilateral filter, the last step, writes the caller's buffers
+    float *wl = refine ? Workspace::get<float>(HW) : d_disp_l, *wr = refine ? Workspace::get<float>(HW) : d_disp_r;
     if (hslo) {
         // Mei et al. 3.3: scanline optimisation of the aggregated cost, then WTA.  Penalty constants: the values the
         // reference's (commented-out) test call uses, image_io.cpp:311-313.  Parity unpinned.
@@ -621,26 +623,24 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
         const Vol cv[2] = {cl, cr};
         const u8 *ia[2] = {img_l, img_r}, *ib[2] = {img_r, img_l}; // the right view's own image plays "left"
         const int os[2] = {1, -1};
-        float *dv[2] = {d_disp_l, d_disp_r};
+        float *dv[2] = {wl, wr};
         launch_hslo_wta(2, cv, ia, ib, os, dv, nullptr, 15.0f, 1.0f, 3.0f, D, zero_disp, H, W, elem_sz);
     } else {
-        core_agg_wta(cl, sc, al, d_disp_l, D, zero_disp, H, W, usd);
-        core_agg_wta(cr, sc, ar, d_disp_r, D, zero_disp, H, W, usd);
+        core_agg_wta(cl, sc, al, wl, D, zero_disp, H, W, usd);
+        core_agg_wta(cr, sc, ar, wr, D, zero_disp, H, W, usd);
     }
     if (!refine) return;
 
-    u8 *outl_l = Workspace::get<u8>(HW), *outl_r = Workspace::get<u8>(HW), *hit_l = Workspace::get<u8>(HW), *hit_r = Workspace::get<u8>(HW);
-    STM_CHECK(hipMemsetAsync(outl_l, 0, HW, stream())); // d_io.cu:138-141
-    STM_CHECK(hipMemsetAsync(outl_r, 0, HW, stream()));
-    launch_dcc(outl_l, outl_r, d_disp_l, d_disp_r, hit_l, hit_r, H, W);
+    u8 *outl_l = Workspace::get<u8>(HW), *outl_r = Workspace::get<u8>(HW);
+    launch_dcc_rows(outl_l, outl_r, wl, wr, H, W); // d_io.cu:138-143 (outlier maps zeroed, dr_dcc)
     {   // d_io.cu:147-148, both views per launch
-        float *dv[2] = {d_disp_l, d_disp_r};
+        float *dv[2] = {wl, wr};
         u8 *ov[2] = {outl_l, outl_r};
         const u8 *u[2] = {al.up, ar.up}, *d[2] = {al.down, ar.down}, *l[2] = {al.left, ar.left}, *r[2] = {al.right, ar.right};
         launch_irv(2, dv, ov, u, d, l, r, thresh_s, thresh_h, H, W, D, zero_disp, usd, 5, true);
     }
-    core_bilateral(d_disp_l, 7, 5.0f, 10.0f, H, W, D); // :150
-    core_bilateral(d_disp_r, 7, 5.0f, 10.0f, H, W, D); // :151
+    launch_bilateral(wl, d_disp_l, gauss2d_table(7, 10.0f), gauss1d_table(D, 5.0f), 7, H, W, D); // :150  (7, 5, 10)
+    launch_bilateral(wr, d_disp_r, gauss2d_table(7, 10.0f), gauss1d_table(D, 5.0f), 7, H, W, D); // :151
 }
 
 // hit maps -> bleed -> masks -> N-2 views -> interlace (d_io.cu:160-205)
@@ -648,14 +648,8 @@ void frame_render(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, u8 *d_
                   int elem_sz, int N, float angle)
 {
     const size_t HW = (size_t)H * W, IMG = HW * elem_sz;
-    u8 *occl_l = Workspace::get<u8>(HW), *occl_r = Workspace::get<u8>(HW), *tmp8 = Workspace::get<u8>(HW);
-    launch_occl(occl_l, occl_r, d_disp_l, d_disp_r, H, W); // :165
-    launch_bleed(occl_l, tmp8, 1, H, W);                   // :167
-    STM_CHECK(hipMemcpyAsync(occl_l, tmp8, HW, hipMemcpyDeviceToDevice, stream()));
-    launch_bleed(occl_r, tmp8, 1, H, W);                   // :168
-    STM_CHECK(hipMemcpyAsync(occl_r, tmp8, HW, hipMemcpyDeviceToDevice, stream()));
     float *mask_l = Workspace::get<float>(HW), *mask_r = Workspace::get<float>(HW), *blend = Workspace::get<float>(HW);
-    launch_occl_to_mask(mask_l, mask_r, occl_l, occl_r, H, W); // :175-176
+    launch_hitmask_rows(mask_l, mask_r, d_disp_l, d_disp_r, H, W); // :165-176: dibr_occl, bleed(1) x2, occl_to_mask
     launch_gaussian_max(mask_r, blend, gauss2d_table(10, 15.0f), 10, 15.0f, H, W, true); // d_dibr_bwarp.cu:60-63, once per frame
 
     u8 *views_mem = Workspace::get<u8>((size_t)N * IMG);

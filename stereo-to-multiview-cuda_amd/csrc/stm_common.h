@@ -116,6 +116,8 @@ void launch_demux_sbs(u8 *l, u8 *r, const u8 *sbs, int H, int Wsbs, int W, int e
 void launch_occl(u8 *occl_l, u8 *occl_r, const float *disp_l, const float *disp_r, int H, int W);
 void launch_bleed(const u8 *in, u8 *out, int radius, int H, int W);
 void launch_median3(const float *in, float *out, int H, int W);
+void launch_dcc_rows(u8 *out_l, u8 *out_r, const float *disp_l, const float *disp_r, int H, int W);
+void launch_hitmask_rows(float *mask_l, float *mask_r, const float *disp_l, const float *disp_r, int H, int W);
 void launch_occl_to_mask(float *mask_l, float *mask_r, const u8 *occl_l, const u8 *occl_r, int H, int W);
 void launch_view_synth(u8 *out, const u8 *img_l, const u8 *img_r, const float *disp_l, const float *disp_r,
                        const float *mask_l, const float *mask_r, const float *blend, float shift, int H, int W, int elem_sz);

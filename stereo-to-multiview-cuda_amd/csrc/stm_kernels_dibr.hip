@@ -133,6 +133,71 @@ void launch_occl_to_mask(float *mask_l, float *mask_r, const u8 *occl_l, const u
     STM_CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------ hit maps -> bleed(1) -> masks, fused (frame pipeline)
+// d_io.cu:165-176 runs dibr_occl, filter_bleed_1(radius 1) on both maps and dibr_occl_to_mask: two zero-fills, the
+// scatter, two stencils with a copy back each, the mask kernel.  The scatter never leaves its image row and the
+// stencil is 3x3, so one block builds the hit maps of the (at most) three rows its output row reads in LDS, applies
+// the majority rule with the reference's border rule and writes both float masks: one launch, no byte planes.
+__global__ __launch_bounds__(256) void stm_k_hitmask_rows(float *__restrict__ mask_l, float *__restrict__ mask_r,
+                                                          const float *__restrict__ disp_l, const float *__restrict__ disp_r,
+                                                          int H, int W)
+{
+    extern __shared__ u8 hm_lds[]; // [3 rows][left W | right W]
+    const int ty = blockIdx.x;
+    int src[3]; // image rows behind window rows -1, 0, +1 (d_filter.cu:124-127: sy < 0 -> -sy, sy > H-1 -> H-1-y, then in range)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int y = j - 1;
+        int sy = ty + y;
+        if (sy < 0) sy = -sy;
+        if (sy > H - 1) sy = H - 1 - y;
+        src[j] = min(max(sy, 0), H - 1);
+    }
+    for (int i = threadIdx.x; i < 6 * W; i += 256) hm_lds[i] = 0; // d_dibr_occl.cu:149-150
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        u8 *ol = hm_lds + (size_t)j * 2 * W, *orr = ol + W;
+        const size_t row = (size_t)src[j] * W;
+        for (int x = threadIdx.x; x < W; x += 256) {
+            int sd = (int)(disp_l[row + x] * 1.0f);
+            orr[min(max(x + sd, 0), W - 1)] = 1; // d_dibr_occl.cu:124-127
+            sd = (int)(disp_r[row + x] * -1.0f);
+            ol[min(max(x + sd, 0), W - 1)] = 1;
+        }
+    }
+    __syncthreads();
+    const size_t orow = (size_t)ty * W;
+    for (int tx = threadIdx.x; tx < W; tx += 256) {
+        int cnt_l = 0, cnt_r = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const u8 *ol = hm_lds + (size_t)j * 2 * W, *orr = ol + W;
+#pragma unroll
+            for (int x = -1; x <= 1; ++x) {
+                int sx = tx + x;
+                if (sx < 0) sx = -sx;
+                if (sx > W - 1) sx = W - 1 - x;
+                sx = min(max(sx, 0), W - 1);
+                cnt_l += ol[sx] > 0;
+                cnt_r += orr[sx] > 0;
+            }
+        }
+        // bleed: count > (9 - 1) * 0.30 -> 1, else the centre value (d_filter.cu:131-137); mask = (value == 1) (d_dibr_occl.cu:17-31)
+        const u8 vl = ((double)cnt_l > 8 * 0.30) ? (u8)1 : hm_lds[2 * W + tx];
+        const u8 vr = ((double)cnt_r > 8 * 0.30) ? (u8)1 : hm_lds[3 * W + tx];
+        mask_l[orow + tx] = vl == 1 ? 1.0f : 0.0f;
+        mask_r[orow + tx] = vr == 1 ? 1.0f : 0.0f;
+    }
+}
+void launch_hitmask_rows(float *mask_l, float *mask_r, const float *disp_l, const float *disp_r, int H, int W)
+{
+    const size_t smem = 6 * (size_t)W;
+    if (smem > 64 * 1024) STM_CHECK(hipFuncSetAttribute((const void *)stm_k_hitmask_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(stm_k_hitmask_rows, dim3(H), dim3(256), smem, stream(), mask_l, mask_r, disp_l, disp_r, H, W);
+    STM_CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------ one synthesised view
 // outL = (u8)(L[sxL] * maskR), sxL = (int)clamp(x + dR * (-shift));  outR = (u8)(R[sxR] * maskL),
 // sxR = (int)clamp(x + dL * (1 - shift))   -- the truncation makes alu_bilinear_interp a nearest fetch

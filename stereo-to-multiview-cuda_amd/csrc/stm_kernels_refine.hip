@@ -58,6 +58,43 @@ void launch_dcc(u8 *out_l, u8 *out_r, const float *disp_l, const float *disp_r, 
     STM_CHECK_LAUNCH();
 }
 
+// The whole L/R check of one image row in one block (frame pipeline): both scatters stay inside the row, so the two
+// hit maps live in LDS instead of in memset global planes, and every pixel's class (0, 1 mismatch, 2 occlusion)
+// is written exactly once -- one launch instead of four memsets and two kernels, same classes (d_dr_dcc.cu:18-82).
+__global__ __launch_bounds__(256) void stm_k_dcc_rows(u8 *__restrict__ out_l, u8 *__restrict__ out_r,
+                                                      const float *__restrict__ disp_l, const float *__restrict__ disp_r, int W)
+{
+    extern __shared__ u8 dcc_lds[]; // hit_l[W] | hit_r[W] | flag_l[W] | flag_r[W]
+    u8 *hit_l = dcc_lds, *hit_r = dcc_lds + W, *flag_l = dcc_lds + 2 * W, *flag_r = dcc_lds + 3 * W;
+    const size_t row = (size_t)blockIdx.x * W;
+    for (int x = threadIdx.x; x < W; x += 256) hit_l[x] = hit_r[x] = 1; // 1 = never hit (:107,111)
+    __syncthreads();
+    const float thresh = 1.0f; // :117
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const float dl = disp_l[row + x];
+        int c = min(max(x + (int)dl, 0), W - 1);
+        flag_l[x] = fabsf(dl - disp_r[row + c]) > thresh;
+        hit_r[c] = 0; // every writer stores 0
+        const float dr = disp_r[row + x];
+        c = min(max(x - (int)dr, 0), W - 1);
+        flag_r[x] = fabsf(dr - disp_l[row + c]) > thresh;
+        hit_l[c] = 0;
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += 256) {
+        out_l[row + x] = flag_l[x] ? (hit_l[x] ? 2 : 1) : 0;
+        out_r[row + x] = flag_r[x] ? (hit_r[x] ? 2 : 1) : 0;
+    }
+}
+// out_l / out_r need no initialisation: every pixel is written
+void launch_dcc_rows(u8 *out_l, u8 *out_r, const float *disp_l, const float *disp_r, int H, int W)
+{
+    const size_t smem = 4 * (size_t)W;
+    if (smem > 64 * 1024) STM_CHECK(hipFuncSetAttribute((const void *)stm_k_dcc_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(stm_k_dcc_rows, dim3(H), dim3(256), smem, stream(), out_l, out_r, disp_l, disp_r, W);
+    STM_CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------ iterative region voting
 // Outliers are few (2 % of a synthetic frame, ~15 % of a real one, fewer every iteration) but each one
 // walks a cross region of ~600 pixels, so a thread per pixel leaves most lanes idle and a thread per
