@@ -102,15 +102,17 @@ bool args_ok(const char *fn, std::initializer_list<Dim> dims)
 
 // ---------------------------------------------------------------- device cores
 // cost init: pack -> census -> fused AD + census + robust combine
+// packed_ready: pk_l / pk_r already hold the BGRX dwords of the two images (launch_demux_sbs_packed)
 void core_ci(const u8 *d_img_l, const u8 *d_img_r, Vol cl, Vol cr, uint32_t *pk_l, uint32_t *pk_r, float ad_coeff,
-             float census_coeff, int D, int zd, int H, int W, int elem_sz)
+             float census_coeff, int D, int zd, int H, int W, int elem_sz, bool packed_ready = false)
 {
     size_t HW = (size_t)H * W;
     uint32_t *cen_l = Workspace::get<uint32_t>(HW), *cen_r = Workspace::get<uint32_t>(HW);
-    launch_pack_bgrx(d_img_l, pk_l, H, W, elem_sz);
-    launch_pack_bgrx(d_img_r, pk_r, H, W, elem_sz);
-    launch_census32(pk_l, cen_l, H, W);
-    launch_census32(pk_r, cen_r, H, W);
+    if (!packed_ready) {
+        launch_pack_bgrx(d_img_l, pk_l, H, W, elem_sz);
+        launch_pack_bgrx(d_img_r, pk_r, H, W, elem_sz);
+    }
+    launch_census32_pair(pk_l, cen_l, pk_r, cen_r, H, W);
     const float *lut = rho_table(ad_coeff, census_coeff);
     launch_cost_init(pk_l, pk_r, cen_l, cen_r, cl, cr, lut, lut + 768, D, zd, H, W);
 }
@@ -594,24 +596,26 @@ void stm_d_demux_sbs(unsigned char *d_img_l, unsigned char *d_img_r, unsigned ch
 namespace {
 
 // cost init .. WTA (.. DCC/IRV/bilateral when `refine`) on one rectified pair already split into L / R
+// pre: optional {BGRX left, BGRX right, wide left, wide right} planes produced together with the split (full-resolution path)
 void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arms &al, Arms &ar, int H, int W, int elem_sz,
                      int D, int zero_disp, float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
-                     int thresh_s, float thresh_h, bool refine, bool hslo = false)
+                     int thresh_s, float thresh_h, bool refine, bool hslo = false, uint32_t *const *pre = nullptr)
 {
     const size_t HW = (size_t)H * W;
     const int NQ = (D + 3) / 4;
     const size_t V = HW * NQ * 4; // volumes are kept quad-interleaved (float4 [NQ][H][W]) inside the frame
     float *cost = Workspace::get<float>(2 * V), *scratch = Workspace::get<float>(V);
-    uint32_t *pk_l = Workspace::get<uint32_t>(HW), *pk_r = Workspace::get<uint32_t>(HW);
+    uint32_t *pk_l = pre ? pre[0] : Workspace::get<uint32_t>(HW), *pk_r = pre ? pre[1] : Workspace::get<uint32_t>(HW);
     Vol cl = vol_quads(cost, HW), cr = vol_quads(cost + V, HW), sc = vol_quads(scratch, HW);
-    core_ci(img_l, img_r, cl, cr, pk_l, pk_r, ad_coeff, census_coeff, D, zero_disp, H, W, elem_sz);
+    core_ci(img_l, img_r, cl, cr, pk_l, pk_r, ad_coeff, census_coeff, D, zero_disp, H, W, elem_sz, pre != nullptr);
 
     al = carve_arms(HW);
     ar = carve_arms(HW);
     {
         const uint32_t *pk[2] = {pk_l, pk_r};
         u8 *u[2] = {al.up, ar.up}, *d[2] = {al.down, ar.down}, *l[2] = {al.left, ar.left}, *r[2] = {al.right, ar.right};
-        launch_cross_arms2(2, pk, u, d, l, r, ucd, lcd, usd, lsd, H, W);
+        const uint32_t *wide[2] = {pre ? pre[2] : nullptr, pre ? pre[3] : nullptr};
+        launch_cross_arms2(2, pk, u, d, l, r, ucd, lcd, usd, lsd, H, W, pre ? wide : nullptr);
     }
     // with refinement the raw WTA maps live in scratch and the bilateral filter, the last step, writes the caller's buffers
     float *wl = refine ? Workspace::get<float>(HW) : d_disp_l, *wr = refine ? Workspace::get<float>(HW) : d_disp_r;
@@ -680,12 +684,19 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
     const size_t V = HW * (size_t)((num_disp + 3) / 4) * 4;
     Workspace::begin(((stages & 0x100) ? 13 : 3) * V * 4 + (size_t)(N + 2) * IMG + 128 * HW + (1u << 20));
     u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
-    launch_demux_sbs(img_l, img_r, d_img_sbs, H, num_cols_sbs, W, elem_sz);
+    uint32_t *pre[4] = {nullptr, nullptr, nullptr, nullptr};
+    const bool fused_split = num_cols_sbs >= 2 * W; // both halves complete: emit the derived pixel formats in the same pass
+    if (fused_split) {
+        for (int i = 0; i < 4; ++i) pre[i] = Workspace::get<uint32_t>(HW);
+        launch_demux_sbs_packed(img_l, img_r, pre[0], pre[1], pre[2], pre[3], d_img_sbs, H, num_cols_sbs, W, elem_sz);
+    } else {
+        launch_demux_sbs(img_l, img_r, d_img_sbs, H, num_cols_sbs, W, elem_sz);
+    }
     Arms al, ar;
     const bool hslo = (stages & 0x100) != 0; // + scanline optimisation between aggregation and WTA (BASELINE config 3)
     stages &= 0xff;
     frame_disparity(img_l, img_r, d_disp_l, d_disp_r, al, ar, H, W, elem_sz, num_disp, zero_disp, ad_coeff, census_coeff, ucd,
-                    lcd, usd, lsd, thresh_s, thresh_h, stages >= 2, hslo);
+                    lcd, usd, lsd, thresh_s, thresh_h, stages >= 2, hslo, fused_split ? pre : nullptr);
     if (stages < 3) return;
     frame_render(img_l, img_r, d_disp_l, d_disp_r, d_interlaced, H, W, num_rows_out, num_cols_out, elem_sz, N, angle);
 }

@@ -87,7 +87,7 @@ template <bool QUAD> __device__ __forceinline__ void store_quad(const Vol &v, in
 // ---- launchers (one per kernel family; definitions next to the kernels) -------------
 // cost init (stm_kernels_cost.hip)
 void launch_pack_bgrx(const u8 *bgr, uint32_t *packed, int H, int W, int elem_sz);
-void launch_census32(const uint32_t *packed, uint32_t *census, int H, int W);
+void launch_census32_pair(const uint32_t *packed_l, uint32_t *census_l, const uint32_t *packed_r, uint32_t *census_r, int H, int W);
 void launch_cost_init(const uint32_t *pk_l, const uint32_t *pk_r, const uint32_t *cen_l, const uint32_t *cen_r,
                       Vol cost_l, Vol cost_r, const float *lut_ad, const float *lut_census,
                       int D, int zd, int H, int W);
@@ -95,7 +95,7 @@ void launch_cost_init(const uint32_t *pk_l, const uint32_t *pk_r, const uint32_t
 void launch_cross_arms(const uint32_t *packed, u8 *up, u8 *down, u8 *left, u8 *right,
                        float ucd, float lcd, int usd, int lsd, int H, int W);
 void launch_cross_arms2(int nviews, const uint32_t *const *packed, u8 *const *up, u8 *const *down, u8 *const *left,
-                        u8 *const *right, float ucd, float lcd, int usd, int lsd, int H, int W);
+                        u8 *const *right, float ucd, float lcd, int usd, int lsd, int H, int W, const uint32_t *const *wide_ready = nullptr);
 void launch_agg_h(Vol in, Vol out, const u8 *armL, const u8 *armR, int D, int H, int W);
 void launch_agg_v(Vol in, Vol out, const u8 *armU, const u8 *armD, int D, int H, int W, int usd);
 void launch_agg_h_wta(Vol in, const u8 *armL, const u8 *armR, float *disp, int D, int zd, int H, int W);
@@ -113,6 +113,9 @@ void launch_gaussian_max(const float *in, float *out, const float *spatial, int 
                          bool invert_input);
 // DIBR + mux (stm_kernels_dibr.hip)
 void launch_demux_sbs(u8 *l, u8 *r, const u8 *sbs, int H, int Wsbs, int W, int elem_sz);
+// same, and the BGRX dwords (launch_pack_bgrx) + wide pixels (launch_cross_arms2) of both halves in the same pass
+void launch_demux_sbs_packed(u8 *l, u8 *r, uint32_t *pk_l, uint32_t *pk_r, uint32_t *wide_l, uint32_t *wide_r, const u8 *sbs, int H,
+                             int Wsbs, int W, int elem_sz);
 void launch_occl(u8 *occl_l, u8 *occl_r, const float *disp_l, const float *disp_r, int H, int W);
 void launch_bleed(const u8 *in, u8 *out, int radius, int H, int W);
 void launch_median3(const float *in, float *out, int H, int W);

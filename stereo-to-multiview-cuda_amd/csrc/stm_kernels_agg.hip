@@ -109,13 +109,17 @@ static uint32_t wide_threshold(float t)
 
 // nviews = 1 or 2: both views of a frame share the launch.  packed[] = BGRX planes (launch_pack_bgrx).
 void launch_cross_arms2(int nviews, const uint32_t *const *packed, u8 *const *up, u8 *const *down, u8 *const *left,
-                        u8 *const *right, float ucd, float lcd, int usd, int lsd, int H, int W)
+                        u8 *const *right, float ucd, float lcd, int usd, int lsd, int H, int W, const uint32_t *const *wide_ready)
 {
     ArmsArgs a;
     const int n = H * W;
     ProfScope p("cross_arms");
     const uint32_t *wide[2];
     for (int v = 0; v < nviews; ++v) {
+        if (wide_ready) { // the caller already holds the wide planes (launch_demux_sbs_packed)
+            wide[v] = wide_ready[v];
+            continue;
+        }
         uint32_t *w = Workspace::get<uint32_t>((size_t)n);
         hipLaunchKernelGGL(stm_k_widen_px, dim3(cdiv(n, 256)), dim3(256), 0, stream(), packed[v], w, n);
         STM_CHECK_LAUNCH();
@@ -134,7 +138,7 @@ void launch_cross_arms2(int nviews, const uint32_t *const *packed, u8 *const *up
 void launch_cross_arms(const uint32_t *packed, u8 *up, u8 *down, u8 *left, u8 *right, float ucd, float lcd, int usd,
                        int lsd, int H, int W)
 {
-    launch_cross_arms2(1, &packed, &up, &down, &left, &right, ucd, lcd, usd, lsd, H, W);
+    launch_cross_arms2(1, &packed, &up, &down, &left, &right, ucd, lcd, usd, lsd, H, W, nullptr);
 }
 
 #define STM_ACC(s, v) { s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w; }

@@ -50,9 +50,13 @@ __device__ __forceinline__ uint32_t grey_of(uint32_t px)
 
 constexpr int CEN_TX = 64, CEN_TY = 4;
 // tile rows y0-1 .. y0+CEN_TY-1+3, cols x0-4 .. x0+CEN_TX-1+4, clamp-to-edge (d_ci_census.cu:39-40)
-__global__ __launch_bounds__(CEN_TX *CEN_TY) void stm_k_census32(const uint32_t *__restrict__ packed,
-                                                                uint32_t *__restrict__ census, int H, int W)
+__global__ __launch_bounds__(CEN_TX *CEN_TY) void stm_k_census32(const uint32_t *__restrict__ packed_a,
+                                                                uint32_t *__restrict__ census_a,
+                                                                const uint32_t *__restrict__ packed_b,
+                                                                uint32_t *__restrict__ census_b, int H, int W)
 {
+    const uint32_t *__restrict__ packed = blockIdx.z ? packed_b : packed_a; // blockIdx.z = view
+    uint32_t *__restrict__ census = blockIdx.z ? census_b : census_a;
     constexpr int TW = CEN_TX + 8, TH = CEN_TY + 4;
     __shared__ u8 g[TH][TW + 4];
     int x0 = blockIdx.x * CEN_TX, y0 = blockIdx.y * CEN_TY;
@@ -83,10 +87,11 @@ __global__ __launch_bounds__(CEN_TX *CEN_TY) void stm_k_census32(const uint32_t 
     census[(size_t)gy * W + gx] = w;
 }
 
-void launch_census32(const uint32_t *packed, uint32_t *census, int H, int W)
+// both images of a pair in one launch
+void launch_census32_pair(const uint32_t *packed_l, uint32_t *census_l, const uint32_t *packed_r, uint32_t *census_r, int H, int W)
 {
-    hipLaunchKernelGGL(stm_k_census32, dim3(cdiv(W, CEN_TX), cdiv(H, CEN_TY)), dim3(CEN_TX, CEN_TY), 0, stream(),
-                       packed, census, H, W);
+    hipLaunchKernelGGL(stm_k_census32, dim3(cdiv(W, CEN_TX), cdiv(H, CEN_TY), 2), dim3(CEN_TX, CEN_TY), 0, stream(),
+                       packed_l, census_l, packed_r, census_r, H, W);
     STM_CHECK_LAUNCH();
 }
 

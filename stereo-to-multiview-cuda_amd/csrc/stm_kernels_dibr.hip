@@ -27,6 +27,31 @@ __global__ __launch_bounds__(256) void stm_k_demux_sbs(u8 *__restrict__ l, u8 *_
     else return;
     d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
 }
+// frame pipeline: the split also emits the two derived pixel formats the disparity stages read, so the frame is
+// touched once (requires Wsbs >= 2 W: every pixel of both halves exists)
+__global__ __launch_bounds__(256) void stm_k_demux_sbs_packed(u8 *__restrict__ l, u8 *__restrict__ r, uint32_t *__restrict__ pk_l,
+                                                              uint32_t *__restrict__ pk_r, uint32_t *__restrict__ wide_l,
+                                                              uint32_t *__restrict__ wide_r, const u8 *__restrict__ sbs, int Wsbs,
+                                                              int W, int elem_sz)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= 2 * W) return;
+    const u8 *s = sbs + ((size_t)y * Wsbs + x) * elem_sz;
+    const bool right = x >= W;
+    const size_t p = (size_t)y * W + (right ? x - W : x);
+    const uint32_t b = s[0], g = s[1], rr = s[2];
+    u8 *d = (right ? r : l) + p * elem_sz;
+    d[0] = (u8)b; d[1] = (u8)g; d[2] = (u8)rr;
+    (right ? pk_r : pk_l)[p] = b | (g << 8) | (rr << 16);
+    (right ? wide_r : wide_l)[p] = b | (g << 10) | (rr << 20);
+}
+void launch_demux_sbs_packed(u8 *l, u8 *r, uint32_t *pk_l, uint32_t *pk_r, uint32_t *wide_l, uint32_t *wide_r, const u8 *sbs, int H,
+                             int Wsbs, int W, int elem_sz)
+{
+    hipLaunchKernelGGL(stm_k_demux_sbs_packed, dim3(cdiv(2 * W, 256), H), dim3(256), 0, stream(), l, r, pk_l, pk_r, wide_l, wide_r,
+                       sbs, Wsbs, W, elem_sz);
+    STM_CHECK_LAUNCH();
+}
 void launch_demux_sbs(u8 *l, u8 *r, const u8 *sbs, int H, int Wsbs, int W, int elem_sz)
 {
     hipLaunchKernelGGL(stm_k_demux_sbs, dim3(cdiv(Wsbs, 256), H), dim3(256), 0, stream(), l, r, sbs, H, Wsbs, W, elem_sz);

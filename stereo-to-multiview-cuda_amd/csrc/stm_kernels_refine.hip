@@ -128,18 +128,23 @@ __device__ __forceinline__ int16_t irv_code(u8 outl, float disp, int zd, int nb)
     return (b >= 0 && b < nb) ? (int16_t)b : (int16_t)-2;
 }
 
-// four pixels per thread (one dword of the u8 outlier map); one global atomic per WAVE that holds any outlier
-__global__ __launch_bounds__(256) void stm_k_irv_compact(IrvArgs a, uint32_t HW, int zd, int nb)
+// four pixels per thread (one dword of the u8 outlier map), 4096 pixels per block; the block's outliers are
+// appended in raster order with ONE global atomic (the counter is a single address: per-wave atomics made this
+// kernel atomic-bound)
+constexpr int IC_T = 1024;
+__global__ __launch_bounds__(IC_T) void stm_k_irv_compact(IrvArgs a, uint32_t HW, int zd, int nb)
 {
+    __shared__ int s_tot[IC_T / 64];
+    __shared__ int s_base;
     const int v = blockIdx.y;
     const u8 *__restrict__ outl = a.outl[v];
     const float *__restrict__ disp = a.disp[v];
     uint32_t *__restrict__ list = a.list[v];
-    const uint32_t p = (blockIdx.x * 256u + threadIdx.x) * 4u;
-    const int lane = threadIdx.x & 63;
+    const uint32_t p = (blockIdx.x * (uint32_t)IC_T + threadIdx.x) * 4u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t w = 0;
     // the same pass packs (outlier flag, disparity) into the 16-bit vote code the vote kernel reads:
-    // one dword of flags + one float4 of disparities in, four codes (8 bytes) out per thread
+    // one dword of flags + one float4 of disparities in, four codes (8 bytes) out per thread and plane
     if (p + 4 <= HW && ((((uintptr_t)outl) & 3) | (((uintptr_t)disp) & 15)) == 0) {
         w = *(const uint32_t *)(outl + p);
         const float4 d = *(const float4 *)(disp + p);
@@ -155,19 +160,24 @@ __global__ __launch_bounds__(256) void stm_k_irv_compact(IrvArgs a, uint32_t HW,
             a.code[v][0][p + j] = a.code[v][1][p + j] = irv_code(o, disp[p + j], zd, nb);
         }
     }
-    int c = ((w & 0xff) != 0) + ((w & 0xff00) != 0) + ((w & 0xff0000) != 0) + ((w & 0xff000000u) != 0);
-    if (__ballot(c != 0) == 0) return; // wave-uniform
+    const int c = ((w & 0xff) != 0) + ((w & 0xff00) != 0) + ((w & 0xff0000) != 0) + ((w & 0xff000000u) != 0);
     int incl = c; // inclusive scan over the wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         int t = __shfl_up(incl, o);
         if (lane >= o) incl += t;
     }
-    const int wave_total = __shfl(incl, 63);
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&a.counts[v][0], wave_total);
-    base = __shfl(base, 0);
-    int k = base + incl - c;
+    if (lane == 63) s_tot[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int i = 0; i < IC_T / 64; ++i) tot += s_tot[i];
+        s_base = tot ? atomicAdd(&a.counts[v][0], tot) : 0;
+    }
+    __syncthreads();
+    int k = s_base + incl - c;
+    for (int i = 0; i < wave; ++i) k += s_tot[i];
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j)
         if ((w >> (8 * j)) & 0xff) list[k++] = p + j;
@@ -365,7 +375,8 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
     }
     ProfScope p("irv");
     STM_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * ncount + 2 * dirty_sz, stream()));
-    hipLaunchKernelGGL(stm_k_irv_compact, dim3((unsigned)((HW + 1023) / 1024), nviews), dim3(256), 0, stream(), a, (uint32_t)HW, zd, nb);
+    hipLaunchKernelGGL(stm_k_irv_compact, dim3((unsigned)((HW + 4 * IC_T - 1) / (4 * IC_T)), nviews), dim3(IC_T), 0, stream(), a, (uint32_t)HW, zd,
+                       nb);
     STM_CHECK_LAUNCH();
     const size_t smem = (size_t)nb * IV_WAVES * 4;
     for (int it = 0; it < rounds; ++it) {
