@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64 * WPB) void stm_k_hslo_lines(HsloLineArgs a, flo
     float prev[DPL], rprev[DPL];
 #pragma unroll
     for (int j = 0; j < DPL; ++j) { prev[j] = inf; rprev[j] = 0.f; }
-    float lprev = 0.f;
+    float lcarry = 0.f; // own-image average at the last position of the previous chunk
     bool started = false;
     const int nchunks = (len + CW - 1) / CW;
     for (int c = 0; c < nchunks; ++c) {
@@ -152,13 +152,22 @@ __global__ __launch_bounds__(64 * WPB) void stm_k_hslo_lines(HsloLineArgs a, flo
             for (int i = lane; i < n + 2 * PAD; i += 64)
                 seg[i] = avg_b[(size_t)line * len + min(max(lo - PAD + i, 0), len - 1)];
         }
-        // own-image averages of the chunk: lane t holds position lo + t, broadcast per step with v_readlane
+        // own-image colour steps of the chunk, classified once per chunk with lane = position: D1 = |avg(p) - avg(p - r)|
+        // is the same for every hypothesis, so its class (0: D1 < T, 1: D1 > T, 2: neither) is broadcast per step
+        // with one v_readlane and the penalty candidates are picked on the scalar unit
         const float lrow = lane < n ? avg_a[(size_t)line * len + lo + lane] : 0.f;
+        int d1cls;
+        {
+            float pred = bwd ? __shfl_down(lrow, 1) : __shfl_up(lrow, 1); // the position walked just before this one
+            if (lane == (bwd ? n - 1 : 0)) pred = lcarry;                   // ... which may be the previous chunk's last
+            const float D1 = fabsf(lrow - pred);
+            d1cls = D1 < T ? 0 : (D1 > T ? 1 : 2);
+            lcarry = __shfl(lrow, bwd ? 0 : n - 1);
+        }
         wave_lds_fence();
         // ---- walk: lane = hypothesis, tile updated in place
         for (int k = 0; k < n; ++k) {
             const int t = bwd ? n - 1 - k : k;
-            const float l0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lrow), t));
             float cc[DPL], r0[DPL];
 #pragma unroll
             for (int j = 0; j < DPL; ++j) {
@@ -172,7 +181,6 @@ __global__ __launch_bounds__(64 * WPB) void stm_k_hslo_lines(HsloLineArgs a, flo
                     prev[j] = lane + 64 * j < D ? cc[j] : inf;
                     rprev[j] = r0[j];
                 }
-                lprev = l0;
                 started = true;
                 continue;
             }
@@ -180,32 +188,45 @@ __global__ __launch_bounds__(64 * WPB) void stm_k_hslo_lines(HsloLineArgs a, flo
 #pragma unroll
             for (int j = 1; j < DPL; ++j) mloc = fminf(mloc, prev[j]);
             const float m = wave_min(mloc); // min_k Cr(p-r, k); absent hypotheses hold +inf
-            const float D1 = fabsf(l0 - lprev);
+            // penalty pairs by the class of D2, given the (uniform) class of D1 -- d_dc_hslo.cu:73-93:
+            //   both < T -> a;  exactly one < T and the other > T -> b;  everything else -> c
+            const int u = __builtin_amdgcn_readlane(d1cls, t);
+            const float P1lt = u == 0 ? P1a : (u == 1 ? P1b : P1c), P2lt = u == 0 ? P2a : (u == 1 ? P2b : P2c); // D2 < T
+            const float P1gt = u == 0 ? P1b : P1c, P2gt = u == 0 ? P2b : P2c;                                     // D2 > T
             float cur[DPL];
 #pragma unroll
             for (int j = 0; j < DPL; ++j) {
                 const int d = lane + 64 * j;
-                // Cr(p-r, d-1) and Cr(p-r, d+1): wave shifts, patched at the 64-lane chunk borders
-                float below = STM_DPP(inf, prev[j], 0x138); // wave_shr:1 : lane i <- lane i-1
-                float above = STM_DPP(inf, prev[j], 0x130); // wave_shl:1 : lane i <- lane i+1
-                if (j > 0) {
-                    const float edge = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prev[j - 1]), 63));
-                    if (lane == 0) below = edge;
-                }
-                if (j + 1 < DPL) {
-                    const float edge = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prev[j + 1]), 0));
-                    if (lane == 63) above = edge;
-                }
                 cur[j] = inf;
                 if (d < D) {
                     const float D2 = fabsf(r0[j] - rprev[j]);
-                    float P1, P2;
-                    if (D1 < T && D2 < T) { P1 = P1a; P2 = P2a; }
-                    else if ((D1 < T && D2 > T) || (D1 > T && D2 < T)) { P1 = P1b; P2 = P2b; }
-                    else { P1 = P1c; P2 = P2c; }
+                    const float P1 = D2 < T ? P1lt : (D2 > T ? P1gt : P1c);
+                    const float P2 = D2 < T ? P2lt : (D2 > T ? P2gt : P2c);
+                    // Cr(p-r, d-1) + P1 and Cr(p-r, d+1) + P1: the wave shift rides on the add (DPP operand); a lane
+                    // without a neighbour keeps +inf, which also covers d = 0 and d = D-1 (hypotheses >= D hold +inf)
+                    float tb = inf, ta = inf;
+                    if (DPL == 1) {
+                        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %2, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                                     "v_add_f32_dpp %1, %2, %3 wave_shl:1 row_mask:0xf bank_mask:0xf"
+                                     : "+v"(tb), "+v"(ta)
+                                     : "v"(prev[j]), "v"(P1));
+                    } else { // several hypotheses per lane: patch the 64-lane chunk borders
+                        float below = STM_DPP(inf, prev[j], 0x138); // wave_shr:1 : lane i <- lane i-1
+                        float above = STM_DPP(inf, prev[j], 0x130); // wave_shl:1 : lane i <- lane i+1
+                        if (j > 0) {
+                            const float edge = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prev[j > 0 ? j - 1 : 0]), 63));
+                            if (lane == 0) below = edge;
+                        }
+                        if (j + 1 < DPL) {
+                            const float edge = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prev[j + 1 < DPL ? j + 1 : j]), 0));
+                            if (lane == 63) above = edge;
+                        }
+                        tb = below + P1;
+                        ta = above + P1;
+                    }
                     float best = prev[j];
-                    if (d > 0) { const float tt = below + P1; if (tt < best) best = tt; }
-                    if (d < D - 1) { const float tt = above + P1; if (tt < best) best = tt; }
+                    if (tb < best) best = tb;
+                    if (ta < best) best = ta;
                     { const float tt = m + P2; if (tt < best) best = tt; }
                     float v = cc[j] + best;
                     v = v - m;
@@ -215,7 +236,6 @@ __global__ __launch_bounds__(64 * WPB) void stm_k_hslo_lines(HsloLineArgs a, flo
             }
 #pragma unroll
             for (int j = 0; j < DPL; ++j) { prev[j] = cur[j]; rprev[j] = r0[j]; }
-            lprev = l0;
         }
         // ---- drain: lane = pixel again
         wave_lds_fence();
