@@ -63,7 +63,11 @@ static inline Vol vol_quads(float *base, size_t stride) { Vol v; v.tab = nullptr
 // pipeline, Vol::quad): one 16-byte access.
 template <bool QUAD> __device__ __forceinline__ float4 load_quad(const Vol &v, int q, int D, size_t idx)
 {
-    if (QUAD) return ((const float4 *)v.base)[(size_t)q * v.plane_stride + idx];
+    if (QUAD) { // the volume is streamed: each element is read once per pass, so do not let it displace the arm planes in L2
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f t = __builtin_nontemporal_load((const v4f *)v.base + (size_t)q * v.plane_stride + idx);
+        return make_float4(t.x, t.y, t.z, t.w);
+    }
     const int d0 = q * 4;
     float4 r;
     r.x = v.plane(d0)[idx];
@@ -72,9 +76,17 @@ template <bool QUAD> __device__ __forceinline__ float4 load_quad(const Vol &v, i
     r.w = d0 + 3 < D ? v.plane(d0 + 3)[idx] : 0.f;
     return r;
 }
-template <bool QUAD> __device__ __forceinline__ void store_quad(const Vol &v, int q, int D, size_t idx, float4 s)
+// STREAM: non-temporal store (the aggregation passes: measured 3-5 % faster; the cost-init kernel, which only writes, is
+// 10 % slower with it and keeps ordinary stores)
+template <bool QUAD, bool STREAM = true> __device__ __forceinline__ void store_quad(const Vol &v, int q, int D, size_t idx, float4 s)
 {
-    if (QUAD) { ((float4 *)v.base)[(size_t)q * v.plane_stride + idx] = s; return; }
+    if (QUAD && !STREAM) { ((float4 *)v.base)[(size_t)q * v.plane_stride + idx] = s; return; }
+    if (QUAD) { // written once, read by the next pass from HBM (530 MB >> L2): streaming store
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f t = {s.x, s.y, s.z, s.w};
+        __builtin_nontemporal_store(t, (v4f *)v.base + (size_t)q * v.plane_stride + idx);
+        return;
+    }
     const int d0 = q * 4;
     v.plane(d0)[idx] = s.x;
     if (d0 + 1 < D) v.plane(d0 + 1)[idx] = s.y;

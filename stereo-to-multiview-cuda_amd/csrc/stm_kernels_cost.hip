@@ -158,8 +158,8 @@ __global__ __launch_bounds__(CI_TX) void stm_k_cost_init(const uint32_t *__restr
                 vr[j] = s_lut_ad[ad_r] + s_lut_c[h_r];
             }
         }
-        store_quad<QUAD>(cost_l, q, D, row + x, make_float4(vl[0], vl[1], vl[2], vl[3]));
-        store_quad<QUAD>(cost_r, q, D, row + x, make_float4(vr[0], vr[1], vr[2], vr[3]));
+        store_quad<QUAD, false>(cost_l, q, D, row + x, make_float4(vl[0], vl[1], vl[2], vl[3]));
+        store_quad<QUAD, false>(cost_r, q, D, row + x, make_float4(vr[0], vr[1], vr[2], vr[3]));
     }
 }
 
