@@ -412,7 +412,8 @@ __global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_gaussian_max_r(const float
     __syncthreads();
     const int gx = x0 + threadIdx.x * 4, gy = y0 + threadIdx.y;
     if (gx >= W || gy >= H) return;
-    float res[4] = {0.f, 0.f, 0.f, 0.f};
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 acc[2] = {{0.f, 0.f}, {0.f, 0.f}}; // pixel pairs (0,1) and (2,3): v_pk_mul_f32 / v_pk_add_f32, same rounding per component
     for (int y = 0; y < KW; ++y) {
         float row[NF];
         const float4 *src = (const float4 *)(tile + (threadIdx.y + y) * TW + threadIdx.x * 4);
@@ -425,13 +426,16 @@ __global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_gaussian_max_r(const float
 #pragma unroll
         for (int x = 0; x < KW; ++x) {
             const float w = krow[x];
+            const f2 w2 = {w, w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float t = row[x + i] * w;
-                res[i] = res[i] + t;
+            for (int h = 0; h < 2; ++h) {
+                const f2 v = {row[x + 2 * h], row[x + 2 * h + 1]};
+                const f2 t = v * w2;
+                acc[h] = acc[h] + t;
             }
         }
     }
+    const float res[4] = {acc[0].x, acc[0].y, acc[1].x, acc[1].y};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (gx + i < W) {
@@ -463,7 +467,11 @@ __global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_bilateral_r(const float *_
     __syncthreads();
     const int gx = x0 + threadIdx.x * 4, gy = y0 + threadIdx.y;
     if (gx >= W || gy >= H) return;
-    float va[4], res[4] = {0.f, 0.f, 0.f, 0.f}, norm[4] = {0.f, 0.f, 0.f, 0.f};
+    // The four pixels are kept as two float2 pairs: weight, norm and result updates are v_pk_mul_f32 / v_pk_add_f32
+    // (two pixels per instruction, each component rounded exactly like the scalar operation it replaces).
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    float va[4];
+    f2 res[2] = {{0.f, 0.f}, {0.f, 0.f}}, norm[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int i = 0; i < 4; ++i) va[i] = tile[(threadIdx.y + R) * TW + threadIdx.x * 4 + i + R];
     for (int y = 0; y < KW; ++y) {
@@ -478,21 +486,25 @@ __global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_bilateral_r(const float *_
 #pragma unroll
         for (int x = 0; x < KW; ++x) {
             const float gs = krow[x];
+            const f2 gs2 = {gs, gs};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float vs = row[x + i];
-                int ci = (int)fabsf(va[i] - vs); // d_filter_bilateral.cu:295
-                ci = min(ci, ncolor - 1);
-                const float w = gs * ck[ci];
-                norm[i] = norm[i] + w;
-                const float t = vs * w;
-                res[i] = res[i] + t;
+            for (int h = 0; h < 2; ++h) {
+                const f2 vs = {row[x + 2 * h], row[x + 2 * h + 1]};
+                int c0 = (int)fabsf(va[2 * h] - vs.x), c1 = (int)fabsf(va[2 * h + 1] - vs.y); // d_filter_bilateral.cu:295
+                c0 = min(c0, ncolor - 1);
+                c1 = min(c1, ncolor - 1);
+                const f2 gc = {ck[c0], ck[c1]};
+                const f2 w = gs2 * gc;
+                norm[h] = norm[h] + w;
+                const f2 t = vs * w;
+                res[h] = res[h] + t;
             }
         }
     }
+    const float r4[4] = {res[0].x, res[0].y, res[1].x, res[1].y}, n4[4] = {norm[0].x, norm[0].y, norm[1].x, norm[1].y};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        if (gx + i < W) out[(size_t)gy * W + gx + i] = res[i] / norm[i];
+        if (gx + i < W) out[(size_t)gy * W + gx + i] = r4[i] / n4[i];
 }
 
 // sum of the weights in tap order, float32, exactly as every pixel's `norm = norm + weight` chain computes it
