@@ -31,9 +31,11 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libstm_oracle.so")
-        if not os.path.exists(so):
-            build()
+        so = os.environ.get("STM_ORACLE_SO")  # e.g. the sanitizer build of `make -C oracle asan`
+        if not so:
+            so = os.path.join(_HERE, "libstm_oracle.so")
+            if not os.path.exists(so):
+                build()
         _LIB = C.CDLL(so)
         _LIB.orc_mux_y_interval.restype = C.c_float
     return _LIB
