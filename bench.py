@@ -139,7 +139,10 @@ def main():
         HW = float(H) * W
         # algorithmic bytes per launch: one un-fused pass over one view = 2V + 2HW;
         # last pass fused with WTA = V + 2HW (arms) + 4HW (disparity out)
-        alg = {"agg_h": 2 * V + 2 * HW, "agg_v": 2 * V + 2 * HW, "agg_hw": V + 2 * HW + 4 * HW,
+        # The frame pipeline launches the first H pass and the fused H + WTA pass once for BOTH views (with HSLO the
+        # four passes run per view and there is no fused WTA pass); the V passes are always one view per launch.
+        both = 1 if (args.stages & 0x100) else 2
+        alg = {"agg_h": both * (2 * V + 2 * HW), "agg_v": 2 * V + 2 * HW, "agg_hw": 2 * (V + 2 * HW + 4 * HW),
                "cost_init": 2 * V + 4 * 4 * HW}
         kern = {}
         for name in ["agg_h", "agg_v", "agg_hw", "cost_init", "cross_arms", "hslo", "wta", "irv", "bilateral", "gaussian_max",

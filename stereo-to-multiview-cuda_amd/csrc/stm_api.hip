@@ -630,8 +630,16 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
         float *dv[2] = {wl, wr};
         launch_hslo_wta(2, cv, ia, ib, os, dv, nullptr, 15.0f, 1.0f, 3.0f, D, zero_disp, H, W, elem_sz);
     } else {
-        core_agg_wta(cl, sc, al, wl, D, zero_disp, H, W, usd);
-        core_agg_wta(cr, sc, ar, wr, D, zero_disp, H, W, usd);
+        // H, V, V per view, then the last H pass + WTA of both views in one launch.  After three passes a view's
+        // data sits in its scratch volume; the right view uses the left view's (now free) cost volume as scratch.
+        float *scratch2 = Workspace::get<float>(V);
+        Vol s2 = vol_quads(scratch2, HW);
+        launch_agg_h2(cl, sc, al.left, al.right, cr, s2, ar.left, ar.right, D, H, W);
+        launch_agg_v(sc, cl, al.up, al.down, D, H, W, usd);
+        launch_agg_v(s2, cr, ar.up, ar.down, D, H, W, usd);
+        launch_agg_v(cl, sc, al.up, al.down, D, H, W, usd);
+        launch_agg_v(cr, s2, ar.up, ar.down, D, H, W, usd);
+        launch_agg_h_wta2(sc, al.left, al.right, wl, s2, ar.left, ar.right, wr, D, zero_disp, H, W);
     }
     if (!refine) return;
 
@@ -682,7 +690,7 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
     const int H = num_rows, W = num_cols, N = num_views;
     const size_t HW = (size_t)H * W, IMG = HW * elem_sz;
     const size_t V = HW * (size_t)((num_disp + 3) / 4) * 4;
-    Workspace::begin(((stages & 0x100) ? 13 : 3) * V * 4 + (size_t)(N + 2) * IMG + 128 * HW + (1u << 20));
+    Workspace::begin(((stages & 0x100) ? 13 : 4) * V * 4 + (size_t)(N + 2) * IMG + 128 * HW + (1u << 20));
     u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
     uint32_t *pre[4] = {nullptr, nullptr, nullptr, nullptr};
     const bool fused_split = num_cols_sbs >= 2 * W; // both halves complete: emit the derived pixel formats in the same pass
@@ -719,7 +727,7 @@ void stm_d_adcensus_stm_2(unsigned char *d_img_sbs, float *d_disp_l, float *d_di
     const int H = num_rows, W = num_cols, h = num_rows_disp, w = num_cols_disp, N = num_views;
     const size_t HW = (size_t)H * W, IMG = HW * elem_sz, hw = (size_t)h * w;
     const size_t V = hw * (size_t)((num_disp + 3) / 4) * 4;
-    Workspace::begin(3 * V * 4 + (size_t)(N + 4) * IMG + 96 * HW + 8 * hw + (1u << 20));
+    Workspace::begin(4 * V * 4 + (size_t)(N + 4) * IMG + 96 * HW + 8 * hw + (1u << 20));
     u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
     launch_demux_sbs(img_l, img_r, d_img_sbs, H, num_cols_sbs, W, elem_sz);
     u8 *low_l = Workspace::get<u8>(hw * elem_sz), *low_r = Workspace::get<u8>(hw * elem_sz);

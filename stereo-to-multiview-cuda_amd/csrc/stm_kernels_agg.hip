@@ -179,11 +179,26 @@ constexpr int AH_QPB = 4; // disparity quads per block (un-fused pass)
 // LDS: float4 tile[W] | u16 arms[W] (armL | armR << 8).  While quad q is being summed out of LDS, quad q+1
 // is already in flight from HBM into registers.  WTA: the running (best cost, best index) of the thread's
 // pixels stay in registers across all quads; the aggregated volume is never written.
+// `second`: the other view of the frame (blockIdx.z = 1); its blocks share the launch so that the tail of one view's
+// blocks overlaps the other view's (the fused WTA pass is one block per image row: 1080 blocks are 1.05 waves of
+// what the chip holds, two launches waste almost a whole wave each).
+struct AggHView {
+    Vol in, out;
+    const u8 *armL, *armR;
+    float *disp;
+};
 template <bool QUAD, bool WTA, int T, int PPT>
 __global__ __launch_bounds__(T) void stm_k_agg_h(Vol in, Vol out, const u8 *__restrict__ armL,
                                                  const u8 *__restrict__ armR, float *__restrict__ disp,
-                                                 int D, int zd, int H, int W, int qpb)
+                                                 int D, int zd, int H, int W, int qpb, AggHView second)
 {
+    if (blockIdx.z) {
+        in = second.in;
+        out = second.out;
+        armL = second.armL;
+        armR = second.armR;
+        disp = second.disp;
+    }
     extern __shared__ float4 smem4[];
     float4 *tile = smem4;
     uint16_t *arms = (uint16_t *)(tile + W);
@@ -254,31 +269,34 @@ __global__ __launch_bounds__(T) void stm_k_agg_h(Vol in, Vol out, const u8 *__re
 static size_t agg_h_smem(int W) { return (size_t)W * 16 + (size_t)((W + 1) & ~1) * 2; }
 
 template <bool QUAD, bool WTA, int T, int PPT>
-static void launch_agg_h_tt(Vol in, Vol out, const u8 *armL, const u8 *armR, float *disp, int D, int zd, int H, int W, int qpb)
+static void launch_agg_h_tt(Vol in, Vol out, const u8 *armL, const u8 *armR, float *disp, int D, int zd, int H, int W, int qpb,
+                            const AggHView *second)
 {
     int nq = (D + 3) / 4;
     size_t smem = agg_h_smem(W);
     allow_lds((const void *)stm_k_agg_h<QUAD, WTA, T, PPT>, smem);
-    hipLaunchKernelGGL((stm_k_agg_h<QUAD, WTA, T, PPT>), dim3(H, cdiv(nq, qpb)), dim3(T), smem, stream(), in, out, armL, armR,
-                       disp, D, zd, H, W, qpb);
+    AggHView none{in, out, armL, armR, disp};
+    hipLaunchKernelGGL((stm_k_agg_h<QUAD, WTA, T, PPT>), dim3(H, cdiv(nq, qpb), second ? 2 : 1), dim3(T), smem, stream(), in, out,
+                       armL, armR, disp, D, zd, H, W, qpb, second ? *second : none);
     STM_CHECK_LAUNCH();
 }
 
 // picks (threads, pixels per thread) so that T * PPT >= W with the smallest register footprint
 template <bool QUAD, bool WTA>
-static void launch_agg_h_t(Vol in, Vol out, const u8 *armL, const u8 *armR, float *disp, int D, int zd, int H, int W, int qpb)
+static void launch_agg_h_t(Vol in, Vol out, const u8 *armL, const u8 *armR, float *disp, int D, int zd, int H, int W, int qpb,
+                           const AggHView *second = nullptr)
 {
     const int hv = (agg_variant() / 100) % 10;
     if (W > 8192) {
         fail("aggregation: num_cols > 8192 is not supported by the row-tile kernel", "W", __FILE__, __LINE__);
         return; // only reached in error mode 1 (record and return)
     }
-    if (hv == 1 && W <= 2048) launch_agg_h_tt<QUAD, WTA, 256, 8>(in, out, armL, armR, disp, D, zd, H, W, qpb);
-    else if (hv == 2 && W <= 2048) launch_agg_h_tt<QUAD, WTA, 1024, 2>(in, out, armL, armR, disp, D, zd, H, W, qpb);
-    else if (W <= 1024) launch_agg_h_tt<QUAD, WTA, 256, 4>(in, out, armL, armR, disp, D, zd, H, W, qpb);
-    else if (W <= 2048) launch_agg_h_tt<QUAD, WTA, 512, 4>(in, out, armL, armR, disp, D, zd, H, W, qpb);
-    else if (W <= 4096) launch_agg_h_tt<QUAD, WTA, 1024, 4>(in, out, armL, armR, disp, D, zd, H, W, qpb);
-    else launch_agg_h_tt<QUAD, WTA, 1024, 8>(in, out, armL, armR, disp, D, zd, H, W, qpb);
+    if (hv == 1 && W <= 2048) launch_agg_h_tt<QUAD, WTA, 256, 8>(in, out, armL, armR, disp, D, zd, H, W, qpb, second);
+    else if (hv == 2 && W <= 2048) launch_agg_h_tt<QUAD, WTA, 1024, 2>(in, out, armL, armR, disp, D, zd, H, W, qpb, second);
+    else if (W <= 1024) launch_agg_h_tt<QUAD, WTA, 256, 4>(in, out, armL, armR, disp, D, zd, H, W, qpb, second);
+    else if (W <= 2048) launch_agg_h_tt<QUAD, WTA, 512, 4>(in, out, armL, armR, disp, D, zd, H, W, qpb, second);
+    else if (W <= 4096) launch_agg_h_tt<QUAD, WTA, 1024, 4>(in, out, armL, armR, disp, D, zd, H, W, qpb, second);
+    else launch_agg_h_tt<QUAD, WTA, 1024, 8>(in, out, armL, armR, disp, D, zd, H, W, qpb, second);
 }
 
 void launch_agg_h(Vol in, Vol out, const u8 *armL, const u8 *armR, int D, int H, int W)
@@ -286,6 +304,16 @@ void launch_agg_h(Vol in, Vol out, const u8 *armL, const u8 *armR, int D, int H,
     ProfScope p("agg_h");
     if (in.quad) launch_agg_h_t<true, false>(in, out, armL, armR, nullptr, D, 0, H, W, AH_QPB);
     else launch_agg_h_t<false, false>(in, out, armL, armR, nullptr, D, 0, H, W, AH_QPB);
+}
+
+// both views of a frame in one launch
+void launch_agg_h2(Vol in_a, Vol out_a, const u8 *armL_a, const u8 *armR_a, Vol in_b, Vol out_b, const u8 *armL_b, const u8 *armR_b,
+                   int D, int H, int W)
+{
+    ProfScope p("agg_h");
+    const AggHView second{in_b, out_b, armL_b, armR_b, nullptr};
+    if (in_a.quad) launch_agg_h_t<true, false>(in_a, out_a, armL_a, armR_a, nullptr, D, 0, H, W, AH_QPB, &second);
+    else launch_agg_h_t<false, false>(in_a, out_a, armL_a, armR_a, nullptr, D, 0, H, W, AH_QPB, &second);
 }
 
 // last horizontal pass fused with WTA: the aggregated volume is consumed in LDS and never written
@@ -296,6 +324,18 @@ void launch_agg_h_wta(Vol in, const u8 *armL, const u8 *armR, float *disp, int D
     ProfScope p("agg_hw");
     if (in.quad) launch_agg_h_t<true, true>(in, none, armL, armR, disp, D, zd, H, W, nq);
     else launch_agg_h_t<false, true>(in, none, armL, armR, disp, D, zd, H, W, nq);
+}
+
+// both views of a frame in one launch (same layout for both volumes)
+void launch_agg_h_wta2(Vol in_a, const u8 *armL_a, const u8 *armR_a, float *disp_a, Vol in_b, const u8 *armL_b, const u8 *armR_b,
+                       float *disp_b, int D, int zd, int H, int W)
+{
+    int nq = (D + 3) / 4;
+    Vol none = vol_slab(nullptr, 0);
+    const AggHView second{in_b, none, armL_b, armR_b, disp_b};
+    ProfScope p("agg_hw");
+    if (in_a.quad) launch_agg_h_t<true, true>(in_a, none, armL_a, armR_a, disp_a, D, zd, H, W, nq, &second);
+    else launch_agg_h_t<false, true>(in_a, none, armL_a, armR_a, disp_a, D, zd, H, W, nq, &second);
 }
 
 // ------------------------------------------------------------------ vertical pass
