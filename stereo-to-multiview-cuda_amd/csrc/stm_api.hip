@@ -125,15 +125,6 @@ void core_agg(Vol cost, Vol scratch, const Arms &a, int D, int H, int W, int usd
     launch_agg_v(cost, scratch, a.up, a.down, D, H, W, usd);
     launch_agg_h(scratch, cost, a.left, a.right, D, H, W);
 }
-// same, but the last pass feeds WTA directly: `cost` ends up holding pass 2 (garbage for callers)
-void core_agg_wta(Vol cost, Vol scratch, const Arms &a, float *disp, int D, int zd, int H, int W, int usd)
-{
-    launch_agg_h(cost, scratch, a.left, a.right, D, H, W);
-    launch_agg_v(scratch, cost, a.up, a.down, D, H, W, usd);
-    launch_agg_v(cost, scratch, a.up, a.down, D, H, W, usd);
-    launch_agg_h_wta(scratch, a.left, a.right, disp, D, zd, H, W);
-}
-
 Arms carve_arms(size_t HW)
 {
     u8 *m = Workspace::get<u8>(4 * HW);

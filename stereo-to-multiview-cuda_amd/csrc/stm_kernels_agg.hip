@@ -317,15 +317,6 @@ void launch_agg_h2(Vol in_a, Vol out_a, const u8 *armL_a, const u8 *armR_a, Vol 
 }
 
 // last horizontal pass fused with WTA: the aggregated volume is consumed in LDS and never written
-void launch_agg_h_wta(Vol in, const u8 *armL, const u8 *armR, float *disp, int D, int zd, int H, int W)
-{
-    int nq = (D + 3) / 4;
-    Vol none = vol_slab(nullptr, 0);
-    ProfScope p("agg_hw");
-    if (in.quad) launch_agg_h_t<true, true>(in, none, armL, armR, disp, D, zd, H, W, nq);
-    else launch_agg_h_t<false, true>(in, none, armL, armR, disp, D, zd, H, W, nq);
-}
-
 // both views of a frame in one launch (same layout for both volumes)
 void launch_agg_h_wta2(Vol in_a, const u8 *armL_a, const u8 *armR_a, float *disp_a, Vol in_b, const u8 *armL_b, const u8 *armR_b,
                        float *disp_b, int D, int zd, int H, int W)
