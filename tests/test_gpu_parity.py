@@ -623,6 +623,26 @@ def test_two_host_threads_share_the_gpu(api, orc, stm):
         assert np.array_equal(got[0], cl) and np.array_equal(got[1], x) and np.array_equal(got[2], a) and np.array_equal(got[3], d)
 
 
+def test_side_by_side_frame_with_an_odd_column(gpu_ready, orc):
+    """num_cols_sbs = 2 * num_cols + 1: the splitter ignores the spare column (d_demux_common.cu:16-31)."""
+    import torch
+    from stm_amd import device_api as dev, synth
+    H, W, D, zd = 37, 45, 10, 5
+    sbs, _ = synth.sbs_frame(H, W, D, zd)
+    sbs = np.ascontiguousarray(np.concatenate([sbs, np.full((H, 1, 3), 200, np.uint8)], axis=1))
+    assert sbs.shape[1] == 2 * W + 1
+    p = dev.FrameParams(num_disp=D, zero_disp=zd, usd=9, lsd=4)
+    dl = torch.zeros(H, W, dtype=torch.float32, device="cuda")
+    dr = torch.zeros_like(dl)
+    out = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+    dev.d_adcensus_stm(torch.from_numpy(sbs).cuda(), dl, dr, out, p, stages=3)
+    torch.cuda.synchronize()
+    want = orc.adcensus_stm(sbs, H, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd, p.usd, p.lsd,
+                            p.thresh_s, p.thresh_h)
+    assert np.array_equal(dl.cpu().numpy(), want["disp_l"]) and np.array_equal(dr.cpu().numpy(), want["disp_r"])
+    assert np.array_equal(out.cpu().numpy(), want["interlaced"])
+
+
 def _fuzz_cases(n, seed):
     rng = np.random.RandomState(seed)
     cases = []
