@@ -290,6 +290,71 @@ def test_full_size_properties_1080p(gpu_ready):
     assert float(dl.max()) <= 0 and float(dr.max()) <= 0
 
 
+def test_full_size_frame_equals_per_stage_device_chain(gpu_ready, stm):
+    """1920x1080, D=64, full frame: the frame pipeline (fused split / L-R check / hit-mask / all-views kernels, two
+    views per launch) must equal, bit for bit, the chain of per-stage device-flavour calls in d_io.cu's order, which
+    runs the separate un-fused kernels.  No oracle involved: a size-independent consistency property."""
+    import ctypes as C
+    import torch
+    from stm_amd import device_api as dev, synth
+    lib = stm.lib()
+    H, W, D, zd = 1080, 1920, 64, 32
+    sbs, _ = synth.sbs_frame(H, W, D, zd)
+    p = dev.FrameParams(num_disp=D, zero_disp=zd)
+    N = p.num_views
+    d_sbs = torch.from_numpy(sbs).cuda()
+    dl = torch.zeros(H, W, dtype=torch.float32, device="cuda")
+    dr = torch.zeros_like(dl)
+    out = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+    dev.d_adcensus_stm(d_sbs, dl, dr, out, p, stages=3)
+    torch.cuda.synchronize()
+
+    P = lambda t: C.c_void_p(t.data_ptr())
+    dL = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+    dR = torch.zeros_like(dL)
+    lib.stm_d_demux_sbs(P(dL), P(dR), P(d_sbs), H, 2 * W, W, 3)                                  # d_io.cu:52-60
+    slab = torch.zeros(2, D, H, W, dtype=torch.float32, device="cuda")
+    tab_l, tab_r = dev.d_ci_adcensus(dL, dR, slab, p.ad_coeff, p.census_coeff, D, zd)             # :74-90
+    scratch = torch.zeros(D, H, W, dtype=torch.float32, device="cuda")
+    cross_l = torch.zeros(4, H, W, dtype=torch.uint8, device="cuda")
+    cross_r = torch.zeros_like(cross_l)
+    dev.d_ca_cross(dL, tab_l, scratch, cross_l, p.ucd, p.lcd, p.usd, p.lsd, D)                    # :116-132
+    dev.d_ca_cross(dR, tab_r, scratch, cross_r, p.ucd, p.lcd, p.usd, p.lsd, D)
+    wl = torch.zeros_like(dl)
+    wr = torch.zeros_like(dl)
+    dev.d_dc_wta(tab_l, wl, D, zd)
+    dev.d_dc_wta(tab_r, wr, D, zd)
+    del slab, scratch
+    ol = torch.zeros(H, W, dtype=torch.uint8, device="cuda")
+    orr = torch.zeros_like(ol)
+    lib.stm_d_dr_dcc(P(ol), P(orr), P(wl), P(wr), H, W)                                          # :138-143
+    xt_l, xt_r = dev.plane_table(cross_l), dev.plane_table(cross_r)
+    lib.stm_d_dr_irv(P(wl), P(ol), P(xt_l), p.thresh_s, p.thresh_h, H, W, D, zd, p.usd, 5)       # :147-148
+    lib.stm_d_dr_irv(P(wr), P(orr), P(xt_r), p.thresh_s, p.thresh_h, H, W, D, zd, p.usd, 5)
+    lib.stm_d_filter_bilateral_1(P(wl), 7, 5.0, 10.0, H, W, D)                                   # :150-151
+    lib.stm_d_filter_bilateral_1(P(wr), 7, 5.0, 10.0, H, W, D)
+    torch.cuda.synchronize()
+    assert torch.equal(dl, wl) and torch.equal(dr, wr)
+
+    occl_l = torch.zeros(H, W, dtype=torch.uint8, device="cuda")
+    occl_r = torch.zeros_like(occl_l)
+    lib.stm_d_dibr_occl(P(occl_l), P(occl_r), P(wl), P(wr), H, W)                                # :165
+    lib.stm_d_filter_bleed_1(P(occl_l), 1, H, W)                                                 # :167-168
+    lib.stm_d_filter_bleed_1(P(occl_r), 1, H, W)
+    ml = torch.zeros_like(dl)
+    mr = torch.zeros_like(dl)
+    lib.stm_d_dibr_occl_to_mask(P(ml), P(mr), P(occl_l), P(occl_r), H, W)                        # :175-176
+    views = [dR] + [torch.zeros_like(dL) for _ in range(N - 2)] + [dL]                           # :182-183
+    for v in range(1, N - 1):
+        shift = float(np.float32(1.0 - (1.0 * np.float32(v)) / (np.float32(N) - 1.0)))           # :189
+        lib.stm_d_dibr_dbm(P(views[v]), P(dL), P(dR), P(wl), P(wr), P(occl_l), P(occl_r), P(ml), P(mr), shift, H, W, 3)
+    vt = torch.tensor([v.data_ptr() for v in views], dtype=torch.int64).cuda()
+    out2 = torch.zeros_like(out)
+    lib.stm_d_mux_multiview(P(vt), P(out2), N, p.angle, H, W, H, W, 3)                            # :203
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+
+
 # ----------------------------------------------------------------------------- edge cases
 EDGE = [
     # H, W, D, zd, usd, lsd
