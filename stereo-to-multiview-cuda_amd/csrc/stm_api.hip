@@ -103,8 +103,10 @@ bool args_ok(const char *fn, std::initializer_list<Dim> dims)
 // ---------------------------------------------------------------- device cores
 // cost init: pack -> census -> fused AD + census + robust combine
 // packed_ready: pk_l / pk_r already hold the BGRX dwords of the two images (launch_demux_sbs_packed)
+// census_out != nullptr: stop after the census planes (returned there) -- the caller computes the costs on the fly
 void core_ci(const u8 *d_img_l, const u8 *d_img_r, Vol cl, Vol cr, uint32_t *pk_l, uint32_t *pk_r, float ad_coeff,
-             float census_coeff, int D, int zd, int H, int W, int elem_sz, bool packed_ready = false)
+             float census_coeff, int D, int zd, int H, int W, int elem_sz, bool packed_ready = false,
+             uint32_t **census_out = nullptr)
 {
     size_t HW = (size_t)H * W;
     uint32_t *cen_l = Workspace::get<uint32_t>(HW), *cen_r = Workspace::get<uint32_t>(HW);
@@ -113,6 +115,11 @@ void core_ci(const u8 *d_img_l, const u8 *d_img_r, Vol cl, Vol cr, uint32_t *pk_
         launch_pack_bgrx(d_img_r, pk_r, H, W, elem_sz);
     }
     launch_census32_pair(pk_l, cen_l, pk_r, cen_r, H, W);
+    if (census_out) {
+        census_out[0] = cen_l;
+        census_out[1] = cen_r;
+        return;
+    }
     const float *lut = rho_table(ad_coeff, census_coeff);
     launch_cost_init(pk_l, pk_r, cen_l, cen_r, cl, cr, lut, lut + 768, D, zd, H, W);
 }
@@ -598,7 +605,11 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
     float *cost = Workspace::get<float>(2 * V), *scratch = Workspace::get<float>(V);
     uint32_t *pk_l = pre ? pre[0] : Workspace::get<uint32_t>(HW), *pk_r = pre ? pre[1] : Workspace::get<uint32_t>(HW);
     Vol cl = vol_quads(cost, HW), cr = vol_quads(cost + V, HW), sc = vol_quads(scratch, HW);
-    core_ci(img_l, img_r, cl, cr, pk_l, pk_r, ad_coeff, census_coeff, D, zero_disp, H, W, elem_sz, pre != nullptr);
+    // without HSLO the first aggregation pass computes the initial costs itself (stm_k_agg_h COST mode) and the 2 V of
+    // initial costs are never written; the HSLO path and the per-stage API materialise them with stm_k_cost_init
+    uint32_t *cen[2] = {nullptr, nullptr};
+    core_ci(img_l, img_r, cl, cr, pk_l, pk_r, ad_coeff, census_coeff, D, zero_disp, H, W, elem_sz, pre != nullptr,
+            hslo ? nullptr : cen);
 
     al = carve_arms(HW);
     ar = carve_arms(HW);
@@ -625,7 +636,8 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
         // data sits in its scratch volume; the right view uses the left view's (now free) cost volume as scratch.
         float *scratch2 = Workspace::get<float>(V);
         Vol s2 = vol_quads(scratch2, HW);
-        launch_agg_h2(cl, sc, al.left, al.right, cr, s2, ar.left, ar.right, D, H, W);
+        launch_agg_h2_cost(pk_l, cen[0], pk_r, cen[1], rho_table(ad_coeff, census_coeff), sc, al.left, al.right, s2, ar.left, ar.right,
+                           D, zero_disp, H, W);
         launch_agg_v(sc, cl, al.up, al.down, D, H, W, usd);
         launch_agg_v(s2, cr, ar.up, ar.down, D, H, W, usd);
         launch_agg_v(cl, sc, al.up, al.down, D, H, W, usd);

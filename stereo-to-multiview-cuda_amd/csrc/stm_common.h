@@ -112,6 +112,9 @@ void launch_agg_h(Vol in, Vol out, const u8 *armL, const u8 *armR, int D, int H,
 void launch_agg_v(Vol in, Vol out, const u8 *armU, const u8 *armD, int D, int H, int W, int usd);
 void launch_agg_h2(Vol in_a, Vol out_a, const u8 *armL_a, const u8 *armR_a, Vol in_b, Vol out_b, const u8 *armL_b, const u8 *armR_b,
                    int D, int H, int W);
+void launch_agg_h2_cost(const uint32_t *pk_l, const uint32_t *cen_l, const uint32_t *pk_r, const uint32_t *cen_r, const float *lut,
+                        Vol out_l, const u8 *armL_l, const u8 *armR_l, Vol out_r, const u8 *armL_r, const u8 *armR_r, int D, int zd,
+                        int H, int W);
 void launch_agg_h_wta2(Vol in_a, const u8 *armL_a, const u8 *armR_a, float *disp_a, Vol in_b, const u8 *armL_b, const u8 *armR_b,
                        float *disp_b, int D, int zd, int H, int W);
 void launch_wta(Vol cost, float *disp, int D, int zd, int H, int W);

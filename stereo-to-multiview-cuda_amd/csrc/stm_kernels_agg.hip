@@ -186,12 +186,27 @@ struct AggHView {
     Vol in, out;
     const u8 *armL, *armR;
     float *disp;
+    // COST mode (first pass of the frame pipeline): the input volume is not read but computed on the fly, as
+    // stm_k_cost_init would have written it -- C(d, x) = rho_ad(|own(x) - other(x')|_1) + rho_c(ham(cen_own(x), cen_other(x')))
+    // with x' = clamp(x + sgn (d - zd)); sgn = +1 for the left view, -1 for the right view (SURVEY A-Q6)
+    const uint32_t *pk_own, *cen_own, *pk_oth, *cen_oth;
+    int sgn;
 };
-template <bool QUAD, bool WTA, int T, int PPT>
+
+// popc(x & 0x7fffffff) + 33 * (x >> 31)  ==  the 64-iteration loop of d_alu.cu:7-15 (SURVEY A-Q1)
+__device__ __forceinline__ int hamdist_low32(uint32_t a, uint32_t b)
+{
+    const uint32_t x = a ^ b;
+    return __popc(x & 0x7fffffffu) + 33 * (int)(x >> 31);
+}
+
+template <bool QUAD, bool WTA, int T, int PPT, bool COST = false>
 __global__ __launch_bounds__(T) void stm_k_agg_h(Vol in, Vol out, const u8 *__restrict__ armL,
                                                  const u8 *__restrict__ armR, float *__restrict__ disp,
-                                                 int D, int zd, int H, int W, int qpb, AggHView second)
+                                                 int D, int zd, int H, int W, int qpb, AggHView first, AggHView second,
+                                                 const float *__restrict__ lut_g)
 {
+    const AggHView &vw = blockIdx.z ? second : first;
     if (blockIdx.z) {
         in = second.in;
         out = second.out;
@@ -209,13 +224,45 @@ __global__ __launch_bounds__(T) void stm_k_agg_h(Vol in, Vol out, const u8 *__re
 
     for (int x = tid; x < W; x += T) arms[x] = (uint16_t)armL[row + x] | ((uint16_t)armR[row + x] << 8);
 
+    // COST: rho tables (766 + 65 floats, host-built: bit-identical to the CPU) behind the arms; this thread's own pixels
+    float *lut_ad = (float *)(arms + ((W + 1) & ~1));
+    float *lut_c = lut_ad + 768;
+    uint32_t pk0[COST ? PPT : 1], cen0[COST ? PPT : 1];
+    if (COST) {
+        for (int i = tid; i < 768 + 65; i += T) lut_ad[i] = lut_g[i];
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int x = min(tid + i * T, W - 1);
+            pk0[i] = vw.pk_own[row + x];
+            cen0[i] = vw.cen_own[row + x];
+        }
+        __syncthreads();
+    }
+    const uint32_t *__restrict__ pk_oth = vw.pk_oth + row, *__restrict__ cen_oth = vw.cen_oth + row;
+    const int sgn = vw.sgn;
+    auto cost_quad = [&](int q, int x, uint32_t p0, uint32_t c0) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = q * 4 + j;
+            v[j] = 0.f;
+            if (d < D) {
+                const int xo = min(max(x + sgn * (d - zd), 0), W - 1); // clamp-to-edge in image coordinates
+                const int ad = (int)__builtin_amdgcn_sad_u8(p0, pk_oth[xo], 0u);
+                const int hd = hamdist_low32(c0, cen_oth[xo]);
+                v[j] = lut_ad[ad] + lut_c[hd];
+            }
+        }
+        return make_float4(v[0], v[1], v[2], v[3]);
+    };
+
     float4 pre[PPT];
     float best_c[WTA ? PPT : 1];
     int best_d[WTA ? PPT : 1];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         const int x = tid + i * T;
-        if (x < W) pre[i] = load_quad<QUAD>(in, q0, D, row + x);
+        if (x < W) pre[i] = COST ? cost_quad(q0, x, pk0[COST ? i : 0], cen0[COST ? i : 0]) : load_quad<QUAD>(in, q0, D, row + x);
         if (WTA) { best_c[i] = 3.402823466e+38f; best_d[i] = 0; }
     }
     for (int q = q0; q < q1; ++q) {
@@ -230,7 +277,7 @@ __global__ __launch_bounds__(T) void stm_k_agg_h(Vol in, Vol out, const u8 *__re
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
                 const int x = tid + i * T;
-                if (x < W) pre[i] = load_quad<QUAD>(in, q + 1, D, row + x);
+                if (x < W) pre[i] = COST ? cost_quad(q + 1, x, pk0[COST ? i : 0], cen0[COST ? i : 0]) : load_quad<QUAD>(in, q + 1, D, row + x);
             }
         }
         const int d0 = q * 4;
@@ -266,37 +313,37 @@ __global__ __launch_bounds__(T) void stm_k_agg_h(Vol in, Vol out, const u8 *__re
     }
 }
 
-static size_t agg_h_smem(int W) { return (size_t)W * 16 + (size_t)((W + 1) & ~1) * 2; }
+static size_t agg_h_smem(int W, bool cost = false) { return (size_t)W * 16 + (size_t)((W + 1) & ~1) * 2 + (cost ? (768 + 72) * 4 : 0); }
 
-template <bool QUAD, bool WTA, int T, int PPT>
+template <bool QUAD, bool WTA, int T, int PPT, bool COST = false>
 static void launch_agg_h_tt(Vol in, Vol out, const u8 *armL, const u8 *armR, float *disp, int D, int zd, int H, int W, int qpb,
-                            const AggHView *second)
+                            const AggHView *first, const AggHView *second, const float *lut)
 {
     int nq = (D + 3) / 4;
-    size_t smem = agg_h_smem(W);
-    allow_lds((const void *)stm_k_agg_h<QUAD, WTA, T, PPT>, smem);
-    AggHView none{in, out, armL, armR, disp};
-    hipLaunchKernelGGL((stm_k_agg_h<QUAD, WTA, T, PPT>), dim3(H, cdiv(nq, qpb), second ? 2 : 1), dim3(T), smem, stream(), in, out,
-                       armL, armR, disp, D, zd, H, W, qpb, second ? *second : none);
+    size_t smem = agg_h_smem(W, COST);
+    allow_lds((const void *)stm_k_agg_h<QUAD, WTA, T, PPT, COST>, smem);
+    AggHView none{in, out, armL, armR, disp, nullptr, nullptr, nullptr, nullptr, 0};
+    hipLaunchKernelGGL((stm_k_agg_h<QUAD, WTA, T, PPT, COST>), dim3(H, cdiv(nq, qpb), second ? 2 : 1), dim3(T), smem, stream(), in,
+                       out, armL, armR, disp, D, zd, H, W, qpb, first ? *first : none, second ? *second : none, lut);
     STM_CHECK_LAUNCH();
 }
 
 // picks (threads, pixels per thread) so that T * PPT >= W with the smallest register footprint
-template <bool QUAD, bool WTA>
+template <bool QUAD, bool WTA, bool COST = false>
 static void launch_agg_h_t(Vol in, Vol out, const u8 *armL, const u8 *armR, float *disp, int D, int zd, int H, int W, int qpb,
-                           const AggHView *second = nullptr)
+                           const AggHView *second = nullptr, const AggHView *first = nullptr, const float *lut = nullptr)
 {
     const int hv = (agg_variant() / 100) % 10;
     if (W > 8192) {
         fail("aggregation: num_cols > 8192 is not supported by the row-tile kernel", "W", __FILE__, __LINE__);
         return; // only reached in error mode 1 (record and return)
     }
-    if (hv == 1 && W <= 2048) launch_agg_h_tt<QUAD, WTA, 256, 8>(in, out, armL, armR, disp, D, zd, H, W, qpb, second);
-    else if (hv == 2 && W <= 2048) launch_agg_h_tt<QUAD, WTA, 1024, 2>(in, out, armL, armR, disp, D, zd, H, W, qpb, second);
-    else if (W <= 1024) launch_agg_h_tt<QUAD, WTA, 256, 4>(in, out, armL, armR, disp, D, zd, H, W, qpb, second);
-    else if (W <= 2048) launch_agg_h_tt<QUAD, WTA, 512, 4>(in, out, armL, armR, disp, D, zd, H, W, qpb, second);
-    else if (W <= 4096) launch_agg_h_tt<QUAD, WTA, 1024, 4>(in, out, armL, armR, disp, D, zd, H, W, qpb, second);
-    else launch_agg_h_tt<QUAD, WTA, 1024, 8>(in, out, armL, armR, disp, D, zd, H, W, qpb, second);
+    if (hv == 1 && W <= 2048) launch_agg_h_tt<QUAD, WTA, 256, 8, COST>(in, out, armL, armR, disp, D, zd, H, W, qpb, first, second, lut);
+    else if (hv == 2 && W <= 2048) launch_agg_h_tt<QUAD, WTA, 1024, 2, COST>(in, out, armL, armR, disp, D, zd, H, W, qpb, first, second, lut);
+    else if (W <= 1024) launch_agg_h_tt<QUAD, WTA, 256, 4, COST>(in, out, armL, armR, disp, D, zd, H, W, qpb, first, second, lut);
+    else if (W <= 2048) launch_agg_h_tt<QUAD, WTA, 512, 4, COST>(in, out, armL, armR, disp, D, zd, H, W, qpb, first, second, lut);
+    else if (W <= 4096) launch_agg_h_tt<QUAD, WTA, 1024, 4, COST>(in, out, armL, armR, disp, D, zd, H, W, qpb, first, second, lut);
+    else launch_agg_h_tt<QUAD, WTA, 1024, 8, COST>(in, out, armL, armR, disp, D, zd, H, W, qpb, first, second, lut);
 }
 
 void launch_agg_h(Vol in, Vol out, const u8 *armL, const u8 *armR, int D, int H, int W)
@@ -311,9 +358,21 @@ void launch_agg_h2(Vol in_a, Vol out_a, const u8 *armL_a, const u8 *armR_a, Vol 
                    int D, int H, int W)
 {
     ProfScope p("agg_h");
-    const AggHView second{in_b, out_b, armL_b, armR_b, nullptr};
+    const AggHView second{in_b, out_b, armL_b, armR_b, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (in_a.quad) launch_agg_h_t<true, false>(in_a, out_a, armL_a, armR_a, nullptr, D, 0, H, W, AH_QPB, &second);
     else launch_agg_h_t<false, false>(in_a, out_a, armL_a, armR_a, nullptr, D, 0, H, W, AH_QPB, &second);
+}
+
+// First pass of the frame pipeline, both views in one launch, with the cost volume computed on the fly instead of read
+// (the frame never writes or re-reads the 2 V of initial costs).  lut = rho tables: [0..765] AD, [768..832] census.
+void launch_agg_h2_cost(const uint32_t *pk_l, const uint32_t *cen_l, const uint32_t *pk_r, const uint32_t *cen_r, const float *lut,
+                        Vol out_l, const u8 *armL_l, const u8 *armR_l, Vol out_r, const u8 *armL_r, const u8 *armR_r, int D, int zd,
+                        int H, int W)
+{
+    ProfScope p("agg_h");
+    const AggHView first{out_l, out_l, armL_l, armR_l, nullptr, pk_l, cen_l, pk_r, cen_r, 1};
+    const AggHView second{out_r, out_r, armL_r, armR_r, nullptr, pk_r, cen_r, pk_l, cen_l, -1};
+    launch_agg_h_t<true, false, true>(out_l, out_l, armL_l, armR_l, nullptr, D, zd, H, W, AH_QPB, &second, &first, lut);
 }
 
 // last horizontal pass fused with WTA: the aggregated volume is consumed in LDS and never written
@@ -323,7 +382,7 @@ void launch_agg_h_wta2(Vol in_a, const u8 *armL_a, const u8 *armR_a, float *disp
 {
     int nq = (D + 3) / 4;
     Vol none = vol_slab(nullptr, 0);
-    const AggHView second{in_b, none, armL_b, armR_b, disp_b};
+    const AggHView second{in_b, none, armL_b, armR_b, disp_b, nullptr, nullptr, nullptr, nullptr, 0};
     ProfScope p("agg_hw");
     if (in_a.quad) launch_agg_h_t<true, true>(in_a, none, armL_a, armR_a, disp_a, D, zd, H, W, nq, &second);
     else launch_agg_h_t<false, true>(in_a, none, armL_a, armR_a, disp_a, D, zd, H, W, nq, &second);
