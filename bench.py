@@ -141,9 +141,11 @@ def main():
         # last pass fused with WTA = V + 2HW (arms) + 4HW (disparity out)
         # The frame pipeline launches the first H pass and the fused H + WTA pass once for BOTH views (with HSLO the
         # four passes run per view and there is no fused WTA pass); the V passes are always one view per launch.
-        both = 1 if (args.stages & 0x100) else 2
-        alg = {"agg_h": both * (2 * V + 2 * HW), "agg_v": 2 * V + 2 * HW, "agg_hw": 2 * (V + 2 * HW + 4 * HW),
-               "cost_init": 2 * V + 4 * 4 * HW}
+        # Without HSLO that first H pass also computes the initial costs on the fly: per view it reads four dword planes
+        # (BGRX + census of both images) and the two arm planes and writes V.
+        hslo = bool(args.stages & 0x100)
+        alg = {"agg_h": (2 * V + 2 * HW) if hslo else 2 * (V + 2 * HW + 16 * HW), "agg_v": 2 * V + 2 * HW,
+               "agg_hw": 2 * (V + 2 * HW + 4 * HW), "cost_init": 2 * V + 4 * 4 * HW}
         kern = {}
         for name in ["agg_h", "agg_v", "agg_hw", "cost_init", "cross_arms", "hslo", "wta", "irv", "bilateral", "gaussian_max",
                      "view_synth", "mux"]:

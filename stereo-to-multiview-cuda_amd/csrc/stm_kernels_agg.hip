@@ -240,8 +240,25 @@ __global__ __launch_bounds__(T) void stm_k_agg_h(Vol in, Vol out, const u8 *__re
     }
     const uint32_t *__restrict__ pk_oth = vw.pk_oth + row, *__restrict__ cen_oth = vw.cen_oth + row;
     const int sgn = vw.sgn;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
     auto cost_quad = [&](int q, int x, uint32_t p0, uint32_t c0) {
         float v[4];
+        // fast path, taken by every wave that is not at an image border: the four matched pixels are four consecutive
+        // dwords, fetched with one 16-byte load per plane instead of four clamped gathers
+        const int xb = x + sgn * (q * 4 - zd), xe = xb + 3 * sgn;
+        const int lo = min(xb, xe);
+        const bool edge = lo < 0 || lo + 3 > W - 1 || q * 4 + 3 >= D;
+        if (__builtin_amdgcn_ballot_w64(edge) == 0) {
+            const u32x4 pp = *(const u32x4 *)(pk_oth + lo), cc = *(const u32x4 *)(cen_oth + lo);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t p1 = sgn > 0 ? pp[j] : pp[3 - j], c1 = sgn > 0 ? cc[j] : cc[3 - j];
+                const int ad = (int)__builtin_amdgcn_sad_u8(p0, p1, 0u);
+                const int hd = hamdist_low32(c0, c1);
+                v[j] = lut_ad[ad] + lut_c[hd];
+            }
+            return make_float4(v[0], v[1], v[2], v[3]);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int d = q * 4 + j;
