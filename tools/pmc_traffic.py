@@ -23,7 +23,12 @@ def per_kernel(path, counter):
 def short(name):
     n = name.split("(")[0].replace("void ", "").replace("stm::", "")
     if "agg_h" in n:
-        return "agg_hw" if "true, true" in n or "false, true" in n else "agg_h"
+        args = n[n.index("<") + 1:n.index(">")].split(", ") if "<" in n else []
+        if len(args) >= 2 and args[1] == "true":
+            return "agg_hw"                       # <QUAD, WTA = true, ...>
+        if len(args) >= 5 and args[4] == "true":
+            return "agg_h_cost"                   # <..., COST = true>: costs computed on the fly, no volume read
+        return "agg_h"
     for k in ("agg_v", "cost_init", "cross_arms", "irv_vote", "bilateral", "gaussian_max", "view_synth", "mux"):
         if k in n:
             return k
@@ -39,7 +44,9 @@ def main():
             continue
         f_raw = fetch.get(k, 0.0) * 1024.0
         w = write.get(k, 0.0) * 1024.0
-        corr = 2.0 if ("agg_" in k or "cost_init" in k) else 1.0
+        # the x2 applies to kernels that stream a quad volume with 16 B/lane loads; the on-the-fly cost pass reads only
+        # dword planes (pixels, census, arms)
+        corr = 2.0 if (("agg_" in k and short(k) != "agg_h_cost") or "cost_init" in k) else 1.0
         out[short(k)] = {"kernel": k.split("(")[0], "fetch_raw_bytes": f_raw, "fetch_correction": corr,
                          "write_bytes": w, "traffic_bytes": f_raw * corr + w}
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
