@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
                     wmax = max(wmax, w);
                     base[u] = (y_top + jb + j) * W + xs;
                     cdv[u] = -1; // -1: no vote (outside the row segment, or an outlier itself)
-                    if (lane < w) cdv[u] = code_pl[base[u] + lane];
+                    if (lane < w) cdv[u] = (code_pl + (uint32_t)base[u])[(uint32_t)lane]; // scalar row pointer + loop-invariant lane offset
                 }
 #pragma unroll
                 for (int u = 0; u < IV_U; ++u) irv_tally(cdv[u], hist, total);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
                     for (int u = 0; u < IV_U; ++u) {
                         for (int c0 = 64; c0 < wd[u]; c0 += 64) {
                             int code = -1;
-                            if (c0 + lane < wd[u]) code = code_pl[base[u] + c0 + lane];
+                            if (c0 + lane < wd[u]) code = code_pl[(uint32_t)base[u] + (uint32_t)(c0 + lane)];
                             irv_tally(code, hist, total);
                         }
                     }
