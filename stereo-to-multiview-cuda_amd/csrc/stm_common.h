@@ -30,6 +30,12 @@ struct Workspace {
     template <class T> static T *get(size_t n) { return (T *)alloc(n * sizeof(T)); }
 };
 
+void *ws_private_create();
+void ws_private_bind(void *ws); // nullptr: back to the thread's shared workspace
+void ws_private_destroy(void *ws);
+void ws_identity(void **base, size_t *cap);
+bool prof_enabled();
+
 // ---- profiling of named kernels with HIP events on the launch stream ----------------
 struct ProfScope {
     ProfScope(const char *name);

@@ -41,11 +41,36 @@ struct WsState {
 };
 static thread_local WsState g_ws[16];
 
+static thread_local WsState *g_ws_bound = nullptr; // a private workspace bound by a frame stream (see below)
+
 static WsState &ws()
 {
+    if (g_ws_bound) return *g_ws_bound;
     int dev = 0;
     STM_CHECK(hipGetDevice(&dev));
     return g_ws[dev & 15];
+}
+
+// A private workspace for an object that replays captured work (stm_stream's hipGraph): its addresses must not move
+// when some other call on the same thread grows the shared slab.
+void *ws_private_create() { return new WsState(); }
+void ws_private_bind(void *p) { g_ws_bound = (WsState *)p; }
+void ws_private_destroy(void *p)
+{
+    WsState *w = (WsState *)p;
+    if (!w) return;
+    if (g_ws_bound == w) g_ws_bound = nullptr;
+    STM_CHECK(hipDeviceSynchronize());
+    for (void *q : w->retired) STM_CHECK(hipFree(q));
+    if (w->base) STM_CHECK(hipFree(w->base));
+    delete w;
+}
+// base address and capacity of the workspace in use: lets a caller notice that a replayed capture went stale
+void ws_identity(void **base, size_t *cap)
+{
+    WsState &w = ws();
+    *base = w.base;
+    *cap = w.cap;
 }
 
 void Workspace::begin(size_t hint)
@@ -100,6 +125,7 @@ struct ProfRec {
     hipEvent_t a, b;
 };
 static bool g_prof_on = false;
+bool prof_enabled() { return g_prof_on; }
 static std::vector<ProfRec> g_prof;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 

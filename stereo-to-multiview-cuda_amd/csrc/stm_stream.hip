@@ -8,6 +8,7 @@
 #include "stm_common.h"
 #include "../../include/stm_hip.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -17,6 +18,12 @@ struct Slot {
     float *d_dl = nullptr, *d_dr = nullptr, *h_dl = nullptr, *h_dr = nullptr;
     hipEvent_t ev_in, ev_done, ev_out;
     bool busy = false;
+    // the slot's frame pipeline as a captured graph: a frame is ~30 launches with fixed arguments (the slot's buffers,
+    // the stream's private workspace), replayed with one hipGraphLaunch
+    hipGraphExec_t gexec = nullptr;
+    void *g_ws_base = nullptr;
+    size_t g_ws_cap = 0;
+    int eager_runs = 0;
 };
 
 struct FrameStream {
@@ -24,6 +31,8 @@ struct FrameStream {
     float angle, ad, ce, ucd, lcd, thresh_h;
     size_t in_sz, out_sz, hw;
     hipStream_t s_in, s_compute, s_out;
+    void *ws = nullptr;  // private workspace: addresses baked into the graphs stay valid
+    bool use_graph = true;
     Slot slot[2];
     long submitted = 0, collected = 0;
 };
@@ -46,6 +55,9 @@ void *stm_stream_create(int num_rows, int num_cols_sbs, int num_cols, int num_ro
     STM_CHECK(hipStreamCreateWithFlags(&f->s_in, hipStreamNonBlocking));
     STM_CHECK(hipStreamCreateWithFlags(&f->s_compute, hipStreamNonBlocking));
     STM_CHECK(hipStreamCreateWithFlags(&f->s_out, hipStreamNonBlocking));
+    f->ws = stm::ws_private_create();
+    const char *g = getenv("STM_STREAM_GRAPH"); // STM_STREAM_GRAPH=0: always launch kernel by kernel
+    f->use_graph = !(g && g[0] == '0');
     for (Slot &s : f->slot) {
         STM_CHECK(hipHostMalloc((void **)&s.h_in, f->in_sz, hipHostMallocDefault));
         STM_CHECK(hipHostMalloc((void **)&s.h_out, f->out_sz, hipHostMallocDefault));
@@ -76,8 +88,36 @@ long stm_stream_submit(void *h, const unsigned char *img_sbs)
     STM_CHECK(hipStreamWaitEvent(f->s_compute, s.ev_in, 0));
     void *prev = stm_get_stream();
     stm_set_stream(f->s_compute);
-    stm_d_adcensus_stm(s.d_in, s.d_dl, s.d_dr, s.d_out, f->H, f->Wsbs, f->W, f->Hout, f->Wout, f->E, f->N, f->angle, f->D, f->zd,
-                       f->ad, f->ce, f->ucd, f->lcd, f->usd, f->lsd, f->thresh_s, f->thresh_h, 3);
+    stm::ws_private_bind(f->ws);
+    auto pipeline = [&]() {
+        stm_d_adcensus_stm(s.d_in, s.d_dl, s.d_dr, s.d_out, f->H, f->Wsbs, f->W, f->Hout, f->Wout, f->E, f->N, f->angle, f->D,
+                           f->zd, f->ad, f->ce, f->ucd, f->lcd, f->usd, f->lsd, f->thresh_s, f->thresh_h, 3);
+    };
+    void *wb = nullptr;
+    size_t wc = 0;
+    stm::ws_identity(&wb, &wc);
+    if (s.gexec && (wb != s.g_ws_base || wc != s.g_ws_cap)) { // cannot happen with a private workspace; never replay stale addresses
+        STM_CHECK(hipGraphExecDestroy(s.gexec));
+        s.gexec = nullptr;
+    }
+    if (s.gexec) {
+        STM_CHECK(hipGraphLaunch(s.gexec, f->s_compute));
+    } else if (f->use_graph && s.eager_runs >= 1 && !stm::prof_enabled()) {
+        // the slot's first frame ran eagerly (it sized the workspace, built the lookup tables, raised the LDS limits), so
+        // nothing in here allocates or synchronises: capture this frame's launches, then run the capture
+        hipGraph_t graph = nullptr;
+        STM_CHECK(hipStreamBeginCapture(f->s_compute, hipStreamCaptureModeThreadLocal));
+        pipeline();
+        STM_CHECK(hipStreamEndCapture(f->s_compute, &graph));
+        STM_CHECK(hipGraphInstantiate(&s.gexec, graph, nullptr, nullptr, 0));
+        STM_CHECK(hipGraphDestroy(graph));
+        stm::ws_identity(&s.g_ws_base, &s.g_ws_cap);
+        STM_CHECK(hipGraphLaunch(s.gexec, f->s_compute));
+    } else {
+        pipeline();
+        ++s.eager_runs;
+    }
+    stm::ws_private_bind(nullptr);
     stm_set_stream(prev);
     STM_CHECK(hipEventRecord(s.ev_done, f->s_compute));
     STM_CHECK(hipStreamWaitEvent(f->s_out, s.ev_done, 0));
@@ -115,7 +155,9 @@ void stm_stream_destroy(void *h)
         STM_CHECK(hipHostFree(s.h_in)); STM_CHECK(hipHostFree(s.h_out)); STM_CHECK(hipHostFree(s.h_dl)); STM_CHECK(hipHostFree(s.h_dr));
         STM_CHECK(hipFree(s.d_in)); STM_CHECK(hipFree(s.d_out)); STM_CHECK(hipFree(s.d_dl)); STM_CHECK(hipFree(s.d_dr));
         STM_CHECK(hipEventDestroy(s.ev_in)); STM_CHECK(hipEventDestroy(s.ev_done)); STM_CHECK(hipEventDestroy(s.ev_out));
+        if (s.gexec) STM_CHECK(hipGraphExecDestroy(s.gexec));
     }
+    stm::ws_private_destroy(f->ws);
     STM_CHECK(hipStreamDestroy(f->s_in)); STM_CHECK(hipStreamDestroy(f->s_compute)); STM_CHECK(hipStreamDestroy(f->s_out));
     delete f;
 }

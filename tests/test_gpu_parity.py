@@ -533,6 +533,33 @@ def test_frame_stream_matches_per_frame_calls(gpu_ready, orc):
     assert np.array_equal(got[3][3], want["interlaced"]) and np.array_equal(got[3][1], want["disp_l"])
 
 
+def test_frame_stream_graph_replay_survives_other_calls(gpu_ready, orc):
+    """From its third frame on a stream slot replays a captured hipGraph whose kernel arguments point into the stream's
+    private workspace.  Other library calls on the same thread -- here a much larger image, which regrows the shared
+    workspace between submissions -- must not disturb it: every frame still equals the per-frame call."""
+    from stm_amd import device_api as dev, host_api, synth, video
+    H, W, D, zd = 48, 80, 8, 4
+    p = dev.FrameParams(num_disp=D, zero_disp=zd, usd=9, lsd=4)
+    frames = [synth.sbs_frame(H, W, D, zd, seed=synth.SEED + 100 + k)[0] for k in range(9)]
+    fs = video.FrameStream(H, W, p)
+    got = []
+    big_l, big_r = rand_pair(300, 500, 77)
+    for k, f in enumerate(frames):
+        if k >= 2:
+            got.append(fs.collect())
+        fs.submit(f)
+        if k in (3, 6):
+            host_api.ci_adcensus(big_l, big_r, 10.0, 30.0, 24, 12)   # grows the thread's shared workspace
+    got.append(fs.collect())
+    got.append(fs.collect())
+    fs.close()
+    assert [g[0] for g in got] == list(range(9))
+    for k, f in enumerate(frames):
+        dl, dr, out = host_api.adcensus_stm(f, W, H, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd,
+                                            p.usd, p.lsd, p.thresh_s, p.thresh_h)
+        assert np.array_equal(got[k][1], dl) and np.array_equal(got[k][2], dr) and np.array_equal(got[k][3], out), k
+
+
 def test_video_cli_roundtrip(gpu_ready, tmp_path):
     import subprocess
     import sys

@@ -2,7 +2,7 @@
   (a) stm_adcensus_stm  - one blocking call per frame: upload, compute, download (the reference's adcensus_stm contract)
   (b) stm_stream_*      - the same frames through the double-buffered stream (upload k+1 || compute k || download k-1)
 bench.py's `value` excludes the transfers; these numbers are what DESIGN.md section 5 quotes beside it.
-Usage (GPU box):  python tools/host_rate.py [frames]
+Usage (GPU box):  python tools/host_rate.py [frames [height width disp]]      (STM_STREAM_GRAPH=0: no hipGraph replay)
 """
 import json
 import os
@@ -16,7 +16,8 @@ import stm_amd
 from stm_amd import device_api as dev, host_api, synth, video
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-H, W, D, zd = 1080, 1920, 64, 32
+H, W, D = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1080, 1920, 64)
+zd = D // 2
 sbs, _ = synth.sbs_frame(H, W, D, zd)
 p = dev.FrameParams(num_disp=D, zero_disp=zd)
 
@@ -53,6 +54,6 @@ while pending:
 dt_stream = (time.perf_counter() - t) / n
 fs.close()
 assert np.array_equal(last[3], ref[2]) and np.array_equal(last[1], ref[0])
-print(json.dumps({"frames": n, "host_call_ms": round(dt_call * 1e3, 3), "host_call_fps": round(1 / dt_call, 1),
+print(json.dumps({"frames": n, "size": [H, W, D], "graph": os.environ.get("STM_STREAM_GRAPH", "1") != "0", "host_call_ms": round(dt_call * 1e3, 3), "host_call_fps": round(1 / dt_call, 1),
                   "stream_ms": round(dt_stream * 1e3, 3), "stream_fps": round(1 / dt_stream, 1),
                   "bytes_in": int(sbs.nbytes), "bytes_out": int(2 * H * W * 4 + H * W * 3)}))
