@@ -220,7 +220,9 @@ void stm_generate_gaussian_kernel(float *kernel, int radius, float sigma);
 /* The reference's video loop (video_io.cpp:144-165) calls adcensus_stm once per decoded frame, serialising upload,
  * compute and download.  A frame stream keeps the same per-frame contract (one side-by-side frame in; disp_l,
  * disp_r and the interlaced frame out, in submission order) over double-buffered pinned/device buffers and three
- * HIP streams, so frame k+1 uploads and frame k-1 downloads while frame k computes.  Parameters as adcensus_stm. */
+ * HIP streams, so frame k+1 uploads and frame k-1 downloads while frame k computes.  From its third frame on each
+ * buffer slot replays the frame's kernel launches as a captured hipGraph (environment STM_STREAM_GRAPH=0 turns
+ * that off).  A stream belongs to the host thread that created it.  Parameters as adcensus_stm. */
 void *stm_stream_create(int num_rows, int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out, int elem_sz,
                         int num_views, float angle, int num_disp, int zero_disp, float ad_coeff, float census_coeff,
                         float ucd, float lcd, int usd, int lsd, int thresh_s, float thresh_h);
