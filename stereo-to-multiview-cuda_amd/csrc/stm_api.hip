@@ -602,9 +602,10 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
     const size_t HW = (size_t)H * W;
     const int NQ = (D + 3) / 4;
     const size_t V = HW * NQ * 4; // volumes are kept quad-interleaved (float4 [NQ][H][W]) inside the frame
-    float *cost = Workspace::get<float>(2 * V), *scratch = Workspace::get<float>(V);
+    const bool matrix_pipe = !hslo && (agg_variant() / 10000) % 10 != 1; // default aggregation path: stm_kernels_aggm.hip
+    float *cost = matrix_pipe ? nullptr : Workspace::get<float>(2 * V), *scratch = matrix_pipe ? nullptr : Workspace::get<float>(V);
     uint32_t *pk_l = pre ? pre[0] : Workspace::get<uint32_t>(HW), *pk_r = pre ? pre[1] : Workspace::get<uint32_t>(HW);
-    Vol cl = vol_quads(cost, HW), cr = vol_quads(cost + V, HW), sc = vol_quads(scratch, HW);
+    Vol cl = vol_quads(cost, HW), cr = vol_quads(cost ? cost + V : nullptr, HW), sc = vol_quads(scratch, HW);
     // without HSLO the first aggregation pass computes the initial costs itself (stm_k_agg_h COST mode) and the 2 V of
     // initial costs are never written; the HSLO path and the per-stage API materialise them with stm_k_cost_init
     uint32_t *cen[2] = {nullptr, nullptr};
@@ -631,8 +632,17 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
         const int os[2] = {1, -1};
         float *dv[2] = {wl, wr};
         launch_hslo_wta(2, cv, ia, ib, os, dv, nullptr, 15.0f, 1.0f, 3.0f, D, zero_disp, H, W, elem_sz);
+    } else if (matrix_pipe) {
+        // the aggregation kernels on the matrix pipe: cost -> H -> V, V -> H + WTA, two PQ-layout volumes per view
+        const size_t VP = pq_volume_floats(D, H, W);
+        float *m = Workspace::get<float>(4 * VP);
+        float *va[2] = {m, m + VP}, *vb[2] = {m + 2 * VP, m + 3 * VP};
+        const uint32_t *pk[2] = {pk_l, pk_r}, *cn[2] = {cen[0], cen[1]};
+        const u8 *u[2] = {al.up, ar.up}, *d[2] = {al.down, ar.down}, *l[2] = {al.left, ar.left}, *r[2] = {al.right, ar.right};
+        float *dv[2] = {wl, wr};
+        launch_aggm_frame(pk, cn, rho_table(ad_coeff, census_coeff), va, vb, u, d, l, r, dv, D, zero_disp, H, W, usd);
     } else {
-        // H, V, V per view, then the last H pass + WTA of both views in one launch.  After three passes a view's
+        // legacy (stm_set_agg_variant(10000)): H, V, V per view on the vector ALU, then the last H pass + WTA of both views in one launch.  After three passes a view's
         // data sits in its scratch volume; the right view uses the left view's (now free) cost volume as scratch.
         float *scratch2 = Workspace::get<float>(V);
         Vol s2 = vol_quads(scratch2, HW);
@@ -692,7 +702,7 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
         return;
     const int H = num_rows, W = num_cols, N = num_views;
     const size_t HW = (size_t)H * W, IMG = HW * elem_sz;
-    const size_t V = HW * (size_t)((num_disp + 3) / 4) * 4;
+    const size_t V = pq_volume_floats(num_disp, H, W); // >= the quad-interleaved volume of the HSLO / legacy paths
     Workspace::begin(((stages & 0x100) ? 13 : 4) * V * 4 + (size_t)(N + 2) * IMG + 128 * HW + (1u << 20));
     u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
     uint32_t *pre[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -729,7 +739,7 @@ void stm_d_adcensus_stm_2(unsigned char *d_img_sbs, float *d_disp_l, float *d_di
         return;
     const int H = num_rows, W = num_cols, h = num_rows_disp, w = num_cols_disp, N = num_views;
     const size_t HW = (size_t)H * W, IMG = HW * elem_sz, hw = (size_t)h * w;
-    const size_t V = hw * (size_t)((num_disp + 3) / 4) * 4;
+    const size_t V = pq_volume_floats(num_disp, h, w);
     Workspace::begin(4 * V * 4 + (size_t)(N + 4) * IMG + 96 * HW + 8 * hw + (1u << 20));
     u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
     launch_demux_sbs(img_l, img_r, d_img_sbs, H, num_cols_sbs, W, elem_sz);

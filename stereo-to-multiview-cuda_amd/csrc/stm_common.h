@@ -157,6 +157,17 @@ void launch_disp_scale(float *out, const float *in, int out_rows, int out_cols, 
 void launch_view_table(u8 **tab, u8 *first, u8 *last, u8 *mem, size_t stride, int N);
 void launch_mux(const u8 *const *d_views, u8 *out, int N, float y_interval, float inv_y_interval, int ymod,
                 int Hin, int Win, int Hout, int Wout, int elem_sz, int variant);
+// aggregation on the matrix pipe (stm_kernels_aggm.hip): the frame pipeline's cost -> H -> V, V -> H + WTA
+struct PQViews { // both views of a frame; a / b = the two PQ volumes of a view
+    const uint32_t *pk[2], *cen[2];
+    float *a[2], *b[2];
+    const u8 *armU[2], *armD[2], *armL[2], *armR[2];
+    float *disp[2];
+};
+size_t pq_volume_floats(int D, int H, int W);
+void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, const float *lut, float *const *vol_a, float *const *vol_b,
+                       const u8 *const *armU, const u8 *const *armD, const u8 *const *armL, const u8 *const *armR, float *const *disp,
+                       int D, int zd, int H, int W, int usd);
 // HSLO (stm_kernels_hslo.hip)
 void launch_hslo_wta(int nviews, const Vol *cost, const u8 *const *img_a, const u8 *const *img_b, const int *osign,
                      float *const *disp, float *const *vol_out, float T, float H1, float H2, int D, int zd, int H, int W,
