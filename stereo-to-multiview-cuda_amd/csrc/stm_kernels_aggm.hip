@@ -33,25 +33,25 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define STM_MFMA(m, b, acc, abid) __builtin_amdgcn_mfma_f32_4x4x1f32(m, b, acc, 2, abid, 0)
 
-__device__ __forceinline__ int wave_min_i(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
-}
 // rotate within each row of 16 lanes (DPP row_ror:n)
 template <int N> __device__ __forceinline__ float row_ror_f(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
 }
 template <int N> __device__ __forceinline__ int row_ror_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xf, 0xf, false); }
-
+// wave-wide min / max as a scalar: butterfly inside the rows of 16 on the DPP path, the four rows through readlane
+__device__ __forceinline__ int wave_min_i(int v)
+{
+    v = min(v, row_ror_i<8>(v)); v = min(v, row_ror_i<4>(v)); v = min(v, row_ror_i<2>(v)); v = min(v, row_ror_i<1>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+    v = max(v, row_ror_i<8>(v)); v = max(v, row_ror_i<4>(v)); v = max(v, row_ror_i<2>(v)); v = max(v, row_ror_i<1>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
 __device__ __forceinline__ f4 nt_load4(const f4 *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void nt_store4(f4 *p, f4 v) { __builtin_nontemporal_store(v, p); }
 
@@ -126,15 +126,27 @@ __global__ __launch_bounds__(PC_TX) void stm_k_pq_cost(PQViews v, const float *_
 // LDS: float4 tile[4 chunks][NG groups][16] | u32 sn[16 NW] (window start relative to the tile | length << 16).
 // Lane l: pt = l / 16 (pixel tile), dq = (l / 4) % 4 (quad of the chunk = step slot of the mask), i = l % 4.
 template <int NW, bool WTA>
-__global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, int H, int W, int G, int NC, int HG)
+__global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, int H, int W, int G, int NC, int HG, int nseg)
 {
     constexpr int NT = 64 * NW, TX = 16 * NW;
     extern __shared__ f4 lds4[];
     const int NG = 4 * NW + 2 * HG;
     f4 *tile = lds4;
     uint32_t *sn = (uint32_t *)(tile + 4 * NG * 16);
-    const int view = blockIdx.z, y = blockIdx.y, tid = threadIdx.x;
-    const int X0seg = blockIdx.x * TX;
+    const int tid = threadIdx.x;
+    // block -> (segment, row, view).  Neighbouring segments of a row share 2 HG groups of input; workgroups are dealt to the 8
+    // XCDs round-robin, so XCD x takes the x-th eighth of the (segment-fastest) list: neighbours run back to back on ONE
+    // XCD and the shared halo is served by that XCD's L2 instead of being fetched from HBM twice.  Placement only affects speed.
+    int view, y, X0seg;
+    {
+        const int per_xcd = (nseg * H * 2 + 7) >> 3;
+        const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        if (logical >= nseg * H * 2) return;
+        X0seg = (logical % nseg) * TX;
+        const int rest = logical / nseg;
+        y = rest % H;
+        view = rest / H;
+    }
     const f4 *__restrict__ in = (const f4 *)(view ? v.a[1] : v.a[0]);
     f4 *__restrict__ out = (f4 *)(view ? v.b[1] : v.b[0]);
     const u8 *__restrict__ armL = view ? v.armL[1] : v.armL[0], *__restrict__ armR = view ? v.armR[1] : v.armR[0];
@@ -167,13 +179,22 @@ __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, 
     for (int cs = 0; cs < ncs; ++cs) {
         const int c0 = cs * 4;
         if (cs) __syncthreads(); // the previous chunk set's readers are done with the tile
-#pragma unroll 1
-        for (int cl = 0; cl < 4; ++cl) {
-            const int c = c0 + cl;
-            const f4 *__restrict__ src = in + (((size_t)c * H + y) * G) * 16;
-            for (int r = tid; r < NG * 16; r += NT) {
+        // tile fill: every load of a batch is issued before the first LDS write (a load-wait-write loop would expose the full
+        // HBM latency once per element); addresses are clamped so that all loads are unconditional, zeros selected afterwards
+        for (int r0 = 0; r0 < NG * 16; r0 += 2 * NT) {
+            f4 tmp[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int cl = k & 3, r = r0 + (k >> 2) * NT + tid;
+                const f4 *__restrict__ rowp = in + ((size_t)min(c0 + cl, NC - 1) * H + y) * G * 16; // uniform: scalar base
+                const int g = min(max(gbase + (r >> 4), 0), G - 1);
+                tmp[k] = nt_load4(rowp + (g * 16 + (r & 15)));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int cl = k & 3, r = r0 + (k >> 2) * NT + tid;
                 const int g = gbase + (r >> 4);
-                tile[cl * NG * 16 + r] = (c < NC && g >= 0 && g < G) ? nt_load4(src + (size_t)g * 16 + (r & 15)) : zero4;
+                if (r < NG * 16) tile[cl * NG * 16 + r] = (c0 + cl < NC && g >= 0 && g < G) ? tmp[k] : zero4;
             }
         }
         __syncthreads();
@@ -255,14 +276,33 @@ __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, 
 }
 
 // ------------------------------------------------------------------ both vertical passes, fused
-// One block = one strip of 4 columns (one group) x one chunk of 16 hypotheses, 2 waves: wave 0 runs the first vertical pass
-// 16 output rows per step, from LDS ring 1 (rows of the input volume) into LDS ring 2; wave 1 runs the second pass LAG
-// steps behind, from ring 2 to HBM.  The intermediate volume never leaves the CU (8 V per frame instead of 12 V).
+// One block = one strip of 4 columns (one group) x one chunk of 16 hypotheses, 2 NTP waves: waves 0..NTP-1 run the first
+// vertical pass, 16 output rows each per step, from LDS ring 1 (rows of the input volume) into LDS ring 2; waves NTP..2NTP-1
+// run the second pass LAG steps behind, from ring 2 to HBM.  The intermediate volume never leaves the CU (8 V per frame
+// instead of 12 V).  NTP = 3: a step is 48 rows, so the second ring needs a lag of only 2 steps and two blocks = 12 waves
+// fit a CU's LDS; with one tile per pass and step it was 6 waves and the dependent MFMA chains ran at a third of their rate.
 // Wave tile = 16 rows x 4 columns x 16 hypotheses: lane l: rt = l / 16 (row tile of 4), dq = (l / 4) % 4, i = l % 4; the four
 // column chains take the four components of each ring float4.  Window of pixel (y, x): rows [y - armU, y + armD).
-constexpr int PV_TS = 16;
-__global__ __launch_bounds__(128) void stm_k_pq_v12(PQViews v, int H, int W, int G, int NC, int usd, int R1, int R2, int LAG)
+// Every global access of a step is issued one step ahead (input rows and the next tile's arm bytes) and the LDS reads of
+// the window loop one iteration ahead.
+struct ArmWords { uint32_t u, d; }; // armU / armD bytes of the lane's row, columns 4g..4g+3
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+// One dword load per plane, always issued (row clamped; when W % 4 != 0 the address is not dword-aligned and the last group's
+// bytes beyond column W - 1 belong to the next row -- they are masked by the caller, and the workspace slab extends past
+// the last plane): the loads of a step must be unconditional for the compiler to count them in its s_waitcnt.
+__device__ __forceinline__ ArmWords load_arm_words(const u8 *__restrict__ armU, const u8 *__restrict__ armD, int yy, int g, int H, int W)
 {
+    const size_t p = (size_t)min(yy, H - 1) * W + 4 * g;
+    ArmWords a;
+    a.u = *(const u32_unaligned *)(armU + p);
+    a.d = *(const u32_unaligned *)(armD + p);
+    return a;
+}
+
+template <int NTP>
+__global__ __launch_bounds__(128 * NTP) void stm_k_pq_v12(PQViews v, int H, int W, int G, int NC, int usd, int R1, int R2, int LAG, int dbg)
+{
+    constexpr int PV_TS = 16 * NTP, NTH = 128 * NTP, LB = 8 * NTP; // rows per step, threads, rows per load batch
     extern __shared__ f4 lds4[];
     f4 *ring1 = lds4, *ring2 = lds4 + R1 * 16;
     const int view = blockIdx.z, c = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
@@ -271,107 +311,128 @@ __global__ __launch_bounds__(128) void stm_k_pq_v12(PQViews v, int H, int W, int
     const u8 *__restrict__ armU = view ? v.armU[1] : v.armU[0], *__restrict__ armD = view ? v.armD[1] : v.armD[0];
     const size_t rstride = (size_t)G * 16; // float4 elements between consecutive rows of the strip
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < (R1 + R2) * 16; i += 128) lds4[i] = zero4; // masked steps multiply ring contents by 0: keep them finite
+    for (int i = tid; i < (R1 + R2) * 16; i += NTH) lds4[i] = zero4; // masked steps multiply ring contents by 0: keep them finite
 
-    const int l = tid & 63, wv = tid >> 6;
+    const int l = tid & 63, wv = (tid >> 6) >= NTP, ti = (tid >> 6) - (wv ? NTP : 0); // pass, tile of the step
     const int rt = l >> 4, dq = (l >> 2) & 3, dd = l & 15;
-    const int nT = (H + PV_TS - 1) / PV_TS;
-    // rows of the input volume: the strip's row r is one 256-B piece; thread t loads piece (t / 16) of a 8-row batch
+    const int nT = (H + 15) >> 4, nS = (nT + NTP - 1) / NTP; // tiles of 16 rows, steps
+    const f4 *ring = wv ? ring2 : ring1;
+    const int R = wv ? R2 : R1;
+    // rows of the input volume: the strip's row r is one 256-B piece; thread t loads piece (t / 16) of a LB-row batch
     const int lrow = tid >> 4;
     __syncthreads();
-    // rows needed by step 0: [0, TS + usd - 1)
-    int loaded = 0;
-    {
-        const int want = min(PV_TS + usd - 1, H);
-        for (int r0 = 0; r0 < want; r0 += 8) {
-            const int r = r0 + lrow;
-            if (r < want) ring1[(r % R1) * 16 + dd] = nt_load4(in + (size_t)r * rstride + dd);
+    // rows needed by step 0: [0, TS + usd - 1); four loads in flight per thread
+    int loaded = min(PV_TS + usd - 1, H);
+    for (int r0 = 0; r0 < loaded; r0 += 4 * LB) {
+        f4 tmp[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tmp[k] = nt_load4(in + (size_t)min(r0 + LB * k + lrow, H - 1) * rstride + dd);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + LB * k + lrow;
+            if (r < loaded) ring1[(r % R1) * 16 + dd] = tmp[k];
         }
-        loaded = want;
     }
-    for (int t = 0; t < nT + LAG; ++t) {
+    int slot_ld = loaded % R1; // ring-1 slot of row `loaded`
+    // this wave's tile of step t is u = NTP t + ti (first pass) or NTP (t - LAG) + ti (second pass); its arm bytes are fetched
+    // one step ahead
+    int u = (wv ? -LAG * NTP : 0) + ti;
+    int slot_rd = (16 * ti) % R, slot_wr = (16 * ti) % R2; // slots of the tile's first row in the ring this wave reads / in ring 2
+    ArmWords nxt = load_arm_words(armU, armD, max(u, 0) * 16 + 4 * rt + (l & 3), g, H, W);
+    for (int t = 0; t < nS + LAG; ++t, u += NTP) {
         __syncthreads(); // ring 1 holds the rows of this step; ring 2 the first-pass rows of the steps before
-        // prefetch the rows the NEXT step adds: [loaded, loaded + TS)
+        // decode this step's arm bytes (loaded a step ago) BEFORE the loads below are issued: no wait on anything recent
+        const int y0 = u * 16;
+        const int yy = y0 + 4 * rt + (l & 3);
+        int s[4], n[4];
+        int lo = 0x7fffffff, hi = -0x7fffffff;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int aU = (int)((nxt.u >> (8 * cc)) & 0xffu), aD = (int)((nxt.d >> (8 * cc)) & 0xffu);
+            s[cc] = yy - aU;
+            n[cc] = (u >= 0 && yy < H && 4 * g + cc < W) ? aU + aD : 0;
+            if (n[cc]) {
+                lo = min(lo, s[cc]);
+                hi = max(hi, s[cc] + n[cc]);
+            }
+        }
+        // rows the NEXT step adds: [loaded, loaded + TS), and the next tile's arm bytes; all unconditional (clamped rows)
         f4 pre[2];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int r = loaded + 8 * k + lrow;
-            pre[k] = (r < H) ? nt_load4(in + (size_t)r * rstride + dd) : zero4;
-        }
-        const int u = wv ? t - LAG : t; // output tile of this wave
+        for (int k = 0; k < 2; ++k) pre[k] = nt_load4(in + (size_t)min(loaded + LB * k + lrow, H - 1) * rstride + dd);
+        nxt = load_arm_words(armU, armD, max(u + NTP, 0) * 16 + 4 * rt + (l & 3), g, H, W);
         if (u >= 0 && u < nT) {
-            const int y0 = u * PV_TS;
-            const f4 *ring = wv ? ring2 : ring1;
-            const int R = wv ? R2 : R1;
-            const int yy = y0 + 4 * rt + (l & 3);
-            int s[4], n[4];
-            int lo = 0x7fffffff, hi = -0x7fffffff;
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int x = 4 * g + cc;
-                s[cc] = yy;
-                n[cc] = 0;
-                if (yy < H && x < W) {
-                    const size_t p = (size_t)yy * W + x;
-                    const int aU = armU[p], aD = armD[p];
-                    s[cc] = yy - aU;
-                    n[cc] = aU + aD;
-                }
-                if (n[cc]) {
-                    lo = min(lo, s[cc] - 4 * rt);
-                    hi = max(hi, s[cc] + n[cc] - 4 * rt);
-                }
-            }
-            lo = wave_min_i(lo);
-            hi = wave_max_i(hi);
+            lo = wave_min_i(lo == 0x7fffffff ? lo : lo - 4 * rt);
+            hi = wave_max_i(hi == -0x7fffffff ? hi : hi - 4 * rt);
             f4 acc[4] = {zero4, zero4, zero4, zero4};
-            if (hi > lo) {
+            if (hi > lo && !(dbg & 1)) {
                 const int K0 = lo & ~3; // multiple of 4 (two's complement floor), as R is: a 4-row read never wraps
                 const int n_it = (hi - K0 + 3) >> 2;
                 int tt[4];
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) tt[cc] = K0 + 4 * rt + dq - s[cc];
-                int sl = (K0 + 4 * rt) % R;
+                int sl = slot_rd + (K0 - y0) + 4 * rt; // K0 - y0 in [-usd - 15, 12]
                 if (sl < 0) sl += R;
-                for (int it = 0; it < n_it; ++it) {
-                    const f4 *p = ring + sl * 16 + dd;
-                    const f4 v0 = p[0], v1 = p[16], v2 = p[32], v3 = p[48];
-                    sl += 4;
-                    if (sl >= R) sl -= R;
-                    float m[4];
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        m[cc] = ((unsigned)tt[cc] < (unsigned)n[cc]) ? 1.0f : 0.0f;
-                        tt[cc] += 4;
-                    }
-                    acc[0] = STM_MFMA(m[0], v0.x, acc[0], 0); acc[1] = STM_MFMA(m[1], v0.y, acc[1], 0);
-                    acc[2] = STM_MFMA(m[2], v0.z, acc[2], 0); acc[3] = STM_MFMA(m[3], v0.w, acc[3], 0);
-                    acc[0] = STM_MFMA(m[0], v1.x, acc[0], 1); acc[1] = STM_MFMA(m[1], v1.y, acc[1], 1);
-                    acc[2] = STM_MFMA(m[2], v1.z, acc[2], 1); acc[3] = STM_MFMA(m[3], v1.w, acc[3], 1);
-                    acc[0] = STM_MFMA(m[0], v2.x, acc[0], 2); acc[1] = STM_MFMA(m[1], v2.y, acc[1], 2);
-                    acc[2] = STM_MFMA(m[2], v2.z, acc[2], 2); acc[3] = STM_MFMA(m[3], v2.w, acc[3], 2);
-                    acc[0] = STM_MFMA(m[0], v3.x, acc[0], 3); acc[1] = STM_MFMA(m[1], v3.y, acc[1], 3);
-                    acc[2] = STM_MFMA(m[2], v3.z, acc[2], 3); acc[3] = STM_MFMA(m[3], v3.w, acc[3], 3);
+                if (sl >= R) sl -= R;
+                const f4 *p = ring + sl * 16 + dd;
+                const f4 *const pend = ring + R * 16 + dd; // this lane's address one ring length on
+                f4 v0 = p[0], v1 = p[16], v2 = p[32], v3 = p[48];
+                f4 w0, w1, w2, w3;
+                // one iteration = 4 window rows: prefetch the next four rows into (N0..N3), mask VALU, 16 MFMAs on (C0..C3)
+#define STM_V_ITER(C0, C1, C2, C3, N0, N1, N2, N3)                                                          \
+    {                                                                                                       \
+        p += 64;                                                                                            \
+        if (p >= pend) p -= R * 16;                                                                         \
+        N0 = p[0]; N1 = p[16]; N2 = p[32]; N3 = p[48];                                                      \
+        const float m0 = ((unsigned)tt[0] < (unsigned)n[0]) ? 1.0f : 0.0f;                                  \
+        const float m1 = ((unsigned)tt[1] < (unsigned)n[1]) ? 1.0f : 0.0f;                                  \
+        const float m2 = ((unsigned)tt[2] < (unsigned)n[2]) ? 1.0f : 0.0f;                                  \
+        const float m3 = ((unsigned)tt[3] < (unsigned)n[3]) ? 1.0f : 0.0f;                                  \
+        tt[0] += 4; tt[1] += 4; tt[2] += 4; tt[3] += 4;                                                     \
+        acc[0] = STM_MFMA(m0, C0.x, acc[0], 0); acc[1] = STM_MFMA(m1, C0.y, acc[1], 0);                     \
+        acc[2] = STM_MFMA(m2, C0.z, acc[2], 0); acc[3] = STM_MFMA(m3, C0.w, acc[3], 0);                     \
+        acc[0] = STM_MFMA(m0, C1.x, acc[0], 1); acc[1] = STM_MFMA(m1, C1.y, acc[1], 1);                     \
+        acc[2] = STM_MFMA(m2, C1.z, acc[2], 1); acc[3] = STM_MFMA(m3, C1.w, acc[3], 1);                     \
+        acc[0] = STM_MFMA(m0, C2.x, acc[0], 2); acc[1] = STM_MFMA(m1, C2.y, acc[1], 2);                     \
+        acc[2] = STM_MFMA(m2, C2.z, acc[2], 2); acc[3] = STM_MFMA(m3, C2.w, acc[3], 2);                     \
+        acc[0] = STM_MFMA(m0, C3.x, acc[0], 3); acc[1] = STM_MFMA(m1, C3.y, acc[1], 3);                     \
+        acc[2] = STM_MFMA(m2, C3.z, acc[2], 3); acc[3] = STM_MFMA(m3, C3.w, acc[3], 3);                     \
+    }
+                for (int it = 0; it + 1 < n_it; it += 2) {
+                    STM_V_ITER(v0, v1, v2, v3, w0, w1, w2, w3)
+                    STM_V_ITER(w0, w1, w2, w3, v0, v1, v2, v3)
                 }
+                if (n_it & 1) STM_V_ITER(v0, v1, v2, v3, w0, w1, w2, w3)
+#undef STM_V_ITER
             }
             // register i of chain cc = out[row y0 + 4 rt + i][column 4 g + cc][hypothesis 16 c + dd]
+            int so = slot_wr + 4 * rt; // ring 2's slot of the output rows (first pass only)
+            if (so >= R2) so -= R2;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = y0 + 4 * rt + i;
                 const f4 o = {acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
                 if (r < H) {
                     if (wv) nt_store4(out + (size_t)r * rstride + dd, o);
-                    else ring2[(r % R2) * 16 + dd] = o;
+                    else ring2[(so + i) * 16 + dd] = o;
                 }
             }
+            slot_rd += PV_TS;
+            if (slot_rd >= R) slot_rd -= R;
+            slot_wr += PV_TS;
+            if (slot_wr >= R2) slot_wr -= R2;
         }
         __syncthreads(); // everyone is done reading ring 1: the oldest TS rows can be replaced
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int r = loaded + 8 * k + lrow;
-            if (r < H) ring1[(r % R1) * 16 + dd] = pre[k];
+            const int r = loaded + LB * k + lrow;
+            int sw = slot_ld + LB * k + lrow;
+            if (sw >= R1) sw -= R1;
+            if (r < H) ring1[sw * 16 + dd] = pre[k];
         }
-        loaded = min(loaded + PV_TS, H + PV_TS); // keeps advancing past H so that later steps load nothing
+        loaded += PV_TS; // keeps advancing past H so that later steps load nothing
+        slot_ld += PV_TS;
+        if (slot_ld >= R1) slot_ld -= R1;
     }
 }
 
@@ -400,28 +461,31 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
         STM_CHECK_LAUNCH();
     }
     constexpr int NW = 8;
-    const int HG = (usd + 3) / 4 + 1, NG = 4 * NW + 2 * HG;
+    const int HG = (usd + 3) / 4, NG = 4 * NW + 2 * HG; // halo groups: ceil(usd / 4) on either side of a segment
+    const int nseg = cdiv(W, 16 * NW), nblk = ((nseg * H * 2 + 7) / 8) * 8;
     const size_t smem_h = (size_t)4 * NG * 256 + 16 * NW * 4;
     {
         ProfScope p("pq_h");
         allow_lds_m((const void *)stm_k_pq_h<NW, false>, smem_h);
-        hipLaunchKernelGGL((stm_k_pq_h<NW, false>), dim3(cdiv(W, 16 * NW), H, 2), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG);
+        hipLaunchKernelGGL((stm_k_pq_h<NW, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
         STM_CHECK_LAUNCH();
     }
     {
         ProfScope p("pq_v12");
-        const int R1 = (PV_TS + 2 * usd + 3) & ~3;
-        const int LAG = (usd > 1 ? (usd - 1 + PV_TS - 1) / PV_TS : 0) + 1;
-        const int R2 = (PV_TS * (LAG + 1) + usd + 3) & ~3;
+        constexpr int NTP = 3, TS = 16 * NTP;
+        const int R1 = (TS + 2 * usd + 3) & ~3;
+        const int LAG = (usd > 1 ? (usd - 1 + TS - 1) / TS : 0) + 1; // the second pass may use first-pass rows of EARLIER steps only
+        const int R2 = (TS * (LAG + 1) + usd + 3) & ~3;
         const size_t smem = (size_t)(R1 + R2) * 256;
-        allow_lds_m((const void *)stm_k_pq_v12, smem);
-        hipLaunchKernelGGL(stm_k_pq_v12, dim3(G, NC, 2), dim3(128), smem, stream(), v, H, W, G, NC, usd, R1, R2, LAG);
+        allow_lds_m((const void *)stm_k_pq_v12<NTP>, smem);
+        hipLaunchKernelGGL(stm_k_pq_v12<NTP>, dim3(G, NC, 2), dim3(128 * NTP), smem, stream(), v, H, W, G, NC, usd, R1, R2, LAG,
+                           (agg_variant() / 100000) % 10);
         STM_CHECK_LAUNCH();
     }
     {
         ProfScope p("pq_hw");
         allow_lds_m((const void *)stm_k_pq_h<NW, true>, smem_h);
-        hipLaunchKernelGGL((stm_k_pq_h<NW, true>), dim3(cdiv(W, 16 * NW), H, 2), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG);
+        hipLaunchKernelGGL((stm_k_pq_h<NW, true>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
         STM_CHECK_LAUNCH();
     }
 }
