@@ -32,6 +32,8 @@ namespace stm {
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define STM_MFMA(m, b, acc, abid) __builtin_amdgcn_mfma_f32_4x4x1f32(m, b, acc, 2, abid, 0)
+#define STM_MFMA16(m, b, acc, abid) __builtin_amdgcn_mfma_f32_16x16x1f32(m, b, acc, 2, abid, 0)
+typedef float f16v __attribute__((ext_vector_type(16)));
 
 // rotate within each row of 16 lanes (DPP row_ror:n)
 template <int N> __device__ __forceinline__ float row_ror_f(float v)
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(PC_TX) void stm_k_pq_cost(PQViews v, const float *_
 // (four pixel tiles of 4) x 64 hypotheses = 4 accumulation chains (one per chunk) that share the mask register.
 // LDS: float4 tile[4 chunks][NG groups][16] | u32 sn[16 NW] (window start relative to the tile | length << 16).
 // Lane l: pt = l / 16 (pixel tile), dq = (l / 4) % 4 (quad of the chunk = step slot of the mask), i = l % 4.
-template <int NW, bool WTA>
+template <int NW, bool WTA, bool NTFILL>
 __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, int H, int W, int G, int NC, int HG, int nseg)
 {
     constexpr int NT = 64 * NW, TX = 16 * NW;
@@ -165,8 +167,13 @@ __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, 
         sn[tid] = e;
     }
 
+    // Wave = 16 pixels x 4 chunks, ONE v_mfma_f32_16x16x1_4B_f32 per window step: block b = chunk, A[m] = mask of pixel m
+    // (CBSZ = 2: the A values of block ABID serve all four blocks, so lanes 16a..16a+15 hold the masks of step a of the current
+    // group), B[n] = cost of hypothesis n of the chunk (lane 16 b + n), D: register 4b + i of lane 16q + n = out[pixel 4q + i]
+    // [chunk b][hypothesis n].  1024 adds per instruction at 8 issue cycles (the 4x4x1 form spends 32 on them), so the 3 mask
+    // instructions and the LDS read of a group hide behind the matrix pipe.
     const int l = tid & 63, w = tid >> 6;
-    const int pt = l >> 4, dq = (l >> 2) & 3, dd = l & 15;
+    const int lb = l >> 4, dd = l & 15; // B operand: chunk / D: pixel quad / A: step of the group;  hypothesis / pixel
     const int X0 = X0seg + 16 * w;
     float bc[4];
     int bd[4];
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, 
                 const int cl = k & 3, r = r0 + (k >> 2) * NT + tid;
                 const f4 *__restrict__ rowp = in + ((size_t)min(c0 + cl, NC - 1) * H + y) * G * 16; // uniform: scalar base
                 const int g = min(max(gbase + (r >> 4), 0), G - 1);
-                tmp[k] = nt_load4(rowp + (g * 16 + (r & 15)));
+                tmp[k] = NTFILL ? nt_load4(rowp + (g * 16 + (r & 15))) : rowp[g * 16 + (r & 15)];
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -200,41 +207,40 @@ __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, 
         __syncthreads();
         if (X0 >= W) continue; // whole wave out of the image (uniform per wave); it still takes part in the barriers
         if (cs == 0) {
-            const uint32_t e = sn[16 * w + 4 * pt + (l & 3)];
+            const uint32_t e = sn[16 * w + dd]; // mask lanes: pixel dd of the wave
             const int srel = (int)(e & 0xffffu);
             nn = (int)(e >> 16);
-            const int lo = nn ? ((srel - 4 * pt) >> 2) : 0x7fffffff;
-            const int hi = nn ? ((srel + nn - 4 * pt + 3) >> 2) : -0x7fffffff;
-            G0r = wave_min_i(lo);
-            const int Gend = wave_max_i(hi);
+            G0r = wave_min_i(nn ? (srel >> 2) : 0x7fffffff);
+            const int Gend = wave_max_i(nn ? ((srel + nn + 3) >> 2) : -0x7fffffff);
             n_it = Gend - G0r; // <= 0 when every window of the wave is empty
-            t0 = 4 * (G0r + pt) + dq - srel;
+            t0 = 4 * G0r + lb - srel;
         }
-        f4 acc[4] = {zero4, zero4, zero4, zero4};
+        f16v acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         {
-            const f4 *p = tile + (G0r + pt) * 16 + dd;
+            const f4 *p = tile + (lb * NG + G0r) * 16 + dd;
             int t = t0;
             for (int it = 0; it < n_it; ++it) {
-                const f4 v0 = p[0], v1 = p[NG * 16], v2 = p[2 * NG * 16], v3 = p[3 * NG * 16];
+                const f4 c4 = *p;
                 p += 16;
                 const float m = ((unsigned)t < (unsigned)nn) ? 1.0f : 0.0f;
                 t += 4;
-                acc[0] = STM_MFMA(m, v0.x, acc[0], 0); acc[1] = STM_MFMA(m, v1.x, acc[1], 0);
-                acc[2] = STM_MFMA(m, v2.x, acc[2], 0); acc[3] = STM_MFMA(m, v3.x, acc[3], 0);
-                acc[0] = STM_MFMA(m, v0.y, acc[0], 1); acc[1] = STM_MFMA(m, v1.y, acc[1], 1);
-                acc[2] = STM_MFMA(m, v2.y, acc[2], 1); acc[3] = STM_MFMA(m, v3.y, acc[3], 1);
-                acc[0] = STM_MFMA(m, v0.z, acc[0], 2); acc[1] = STM_MFMA(m, v1.z, acc[1], 2);
-                acc[2] = STM_MFMA(m, v2.z, acc[2], 2); acc[3] = STM_MFMA(m, v3.z, acc[3], 2);
-                acc[0] = STM_MFMA(m, v0.w, acc[0], 3); acc[1] = STM_MFMA(m, v1.w, acc[1], 3);
-                acc[2] = STM_MFMA(m, v2.w, acc[2], 3); acc[3] = STM_MFMA(m, v3.w, acc[3], 3);
+                acc = STM_MFMA16(m, c4.x, acc, 0);
+                acc = STM_MFMA16(m, c4.y, acc, 1);
+                acc = STM_MFMA16(m, c4.z, acc, 2);
+                acc = STM_MFMA16(m, c4.w, acc, 3);
             }
         }
-        // register i of lane l = out[pixel X0 + 4 pt + i][hypothesis 16 (c0 + cl) + dd]
+        // registers 4b..4b+3 of lane 16q + n = out[pixels X0 + 4q .. +3][hypothesis 16 (c0 + b) + n]
         if (!WTA) {
-            if ((X0 >> 2) + pt < G) {
+            if ((X0 >> 2) + lb < G) {
 #pragma unroll
                 for (int cl = 0; cl < 4; ++cl)
-                    if (c0 + cl < NC) nt_store4(out + (((size_t)(c0 + cl) * H + y) * G + (X0 >> 2)) * 16 + l, acc[cl]);
+                    if (c0 + cl < NC) {
+                        const f4 o = {acc[4 * cl], acc[4 * cl + 1], acc[4 * cl + 2], acc[4 * cl + 3]};
+                        nt_store4(out + (((size_t)(c0 + cl) * H + y) * G + (X0 >> 2)) * 16 + l, o);
+                    }
             }
         } else {
             // first strictly-lowest cost wins, ascending d (d_dc_wta.cu:19-34): per lane the chunks come in ascending d
@@ -244,13 +250,13 @@ __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, 
                 if (d < D) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (bc[i] > acc[cl][i]) { bc[i] = acc[cl][i]; bd[i] = d; }
+                        if (bc[i] > acc[4 * cl + i]) { bc[i] = acc[4 * cl + i]; bd[i] = d; }
                 }
             }
         }
     }
     if (WTA && X0 < W) {
-        // across the 16 lanes (dd) of a pixel tile: lowest cost, ties to the lowest d
+        // across the 16 lanes (hypotheses n) of a pixel quad: lowest cost, ties to the lowest d
         float res[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, 
             res[i] = (float)cand - (float)zd;
         }
         if (dd == 0) {
-            const int x = X0 + 4 * pt;
+            const int x = X0 + 4 * lb;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (x + i < W) disp[row + x + i] = res[i];
@@ -303,118 +309,114 @@ template <int NTP>
 __global__ __launch_bounds__(128 * NTP) void stm_k_pq_v12(PQViews v, int H, int W, int G, int NC, int usd, int R1, int R2, int LAG, int dbg)
 {
     constexpr int PV_TS = 16 * NTP, NTH = 128 * NTP, LB = 8 * NTP; // rows per step, threads, rows per load batch
-    extern __shared__ f4 lds4[];
-    f4 *ring1 = lds4, *ring2 = lds4 + R1 * 16;
+    extern __shared__ float ldsf[];
+    // rings of rows; a row = float [4 columns][16 hypotheses] (256 B): lane 16 b + n of a wave reads its B operand linearly
+    float *ring1 = ldsf, *ring2 = ldsf + R1 * 64;
     const int view = blockIdx.z, c = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const f4 *__restrict__ in = (const f4 *)(view ? v.b[1] : v.b[0]) + ((size_t)c * H * G + g) * 16;
     f4 *__restrict__ out = (f4 *)(view ? v.a[1] : v.a[0]) + ((size_t)c * H * G + g) * 16;
     const u8 *__restrict__ armU = view ? v.armU[1] : v.armU[0], *__restrict__ armD = view ? v.armD[1] : v.armD[0];
     const size_t rstride = (size_t)G * 16; // float4 elements between consecutive rows of the strip
-    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < (R1 + R2) * 16; i += NTH) lds4[i] = zero4; // masked steps multiply ring contents by 0: keep them finite
+    for (int i = tid; i < (R1 + R2) * 64; i += NTH) ldsf[i] = 0.f; // masked steps multiply ring contents by 0: keep them finite
 
     const int l = tid & 63, wv = (tid >> 6) >= NTP, ti = (tid >> 6) - (wv ? NTP : 0); // pass, tile of the step
-    const int rt = l >> 4, dq = (l >> 2) & 3, dd = l & 15;
+    const int lb = l >> 4, dd = l & 15; // A: column / row;  B: column / hypothesis;  D: row quad / hypothesis
     const int nT = (H + 15) >> 4, nS = (nT + NTP - 1) / NTP; // tiles of 16 rows, steps
-    const f4 *ring = wv ? ring2 : ring1;
+    const float *ring = wv ? ring2 : ring1;
     const int R = wv ? R2 : R1;
     // rows of the input volume: the strip's row r is one 256-B piece; thread t loads piece (t / 16) of a LB-row batch
-    const int lrow = tid >> 4;
+    const int lrow = tid >> 4, ldd = tid & 15;
     __syncthreads();
     // rows needed by step 0: [0, TS + usd - 1); four loads in flight per thread
     int loaded = min(PV_TS + usd - 1, H);
     for (int r0 = 0; r0 < loaded; r0 += 4 * LB) {
         f4 tmp[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) tmp[k] = nt_load4(in + (size_t)min(r0 + LB * k + lrow, H - 1) * rstride + dd);
+        for (int k = 0; k < 4; ++k) tmp[k] = nt_load4(in + (size_t)min(r0 + LB * k + lrow, H - 1) * rstride + ldd);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int r = r0 + LB * k + lrow;
-            if (r < loaded) ring1[(r % R1) * 16 + dd] = tmp[k];
+            if (r < loaded) {
+                float *q = ring1 + (r % R1) * 64 + ldd;
+                q[0] = tmp[k].x; q[16] = tmp[k].y; q[32] = tmp[k].z; q[48] = tmp[k].w;
+            }
         }
     }
     int slot_ld = loaded % R1; // ring-1 slot of row `loaded`
+    // input rows travel two steps ahead of their use (HBM latency under load exceeds one step): `pre` holds the rows the NEXT
+    // step adds (issued one step ago, written to the ring at the end of this step), `far` the rows of the step after that
+    f4 pre[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) pre[k] = nt_load4(in + (size_t)min(loaded + LB * k + lrow, H - 1) * rstride + ldd);
     // this wave's tile of step t is u = NTP t + ti (first pass) or NTP (t - LAG) + ti (second pass); its arm bytes are fetched
-    // one step ahead
+    // one step ahead: every lane fetches the dword (columns 4g..4g+3) of row (lane % 16) and keeps the byte of its column
     int u = (wv ? -LAG * NTP : 0) + ti;
     int slot_rd = (16 * ti) % R, slot_wr = (16 * ti) % R2; // slots of the tile's first row in the ring this wave reads / in ring 2
-    ArmWords nxt = load_arm_words(armU, armD, max(u, 0) * 16 + 4 * rt + (l & 3), g, H, W);
+    ArmWords nxt = load_arm_words(armU, armD, max(u, 0) * 16 + dd, g, H, W);
+    // window of this lane's pixel (row y0 + dd, column 4g + lb) of the tile about to be computed: [s0, s0 + nn), decoded from
+    // the arm bytes at the END of the step before -- there the only younger loads in flight are that step's two row loads, so
+    // the wait for the bytes (s_waitcnt counts in issue order) does not drag the rows in
+    int s0, nn;
+#define STM_V_DECODE(U)                                                                                  \
+    {                                                                                                    \
+        const int yy_ = (U) * 16 + dd;                                                                   \
+        const int aU_ = (int)((nxt.u >> (8 * lb)) & 0xffu), aD_ = (int)((nxt.d >> (8 * lb)) & 0xffu);    \
+        s0 = yy_ - aU_;                                                                                  \
+        nn = ((U) >= 0 && yy_ < H && 4 * g + lb < W) ? aU_ + aD_ : 0;                                    \
+    }
+    STM_V_DECODE(u)
     for (int t = 0; t < nS + LAG; ++t, u += NTP) {
         __syncthreads(); // ring 1 holds the rows of this step; ring 2 the first-pass rows of the steps before
-        // decode this step's arm bytes (loaded a step ago) BEFORE the loads below are issued: no wait on anything recent
         const int y0 = u * 16;
-        const int yy = y0 + 4 * rt + (l & 3);
-        int s[4], n[4];
-        int lo = 0x7fffffff, hi = -0x7fffffff;
+        // the next tile's arm bytes, then rows [loaded + TS, loaded + 2 TS); all unconditional (clamped rows)
+        nxt = load_arm_words(armU, armD, max(u + NTP, 0) * 16 + dd, g, H, W);
+        f4 far[2];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const int aU = (int)((nxt.u >> (8 * cc)) & 0xffu), aD = (int)((nxt.d >> (8 * cc)) & 0xffu);
-            s[cc] = yy - aU;
-            n[cc] = (u >= 0 && yy < H && 4 * g + cc < W) ? aU + aD : 0;
-            if (n[cc]) {
-                lo = min(lo, s[cc]);
-                hi = max(hi, s[cc] + n[cc]);
-            }
-        }
-        // rows the NEXT step adds: [loaded, loaded + TS), and the next tile's arm bytes; all unconditional (clamped rows)
-        f4 pre[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) pre[k] = nt_load4(in + (size_t)min(loaded + LB * k + lrow, H - 1) * rstride + dd);
-        nxt = load_arm_words(armU, armD, max(u + NTP, 0) * 16 + 4 * rt + (l & 3), g, H, W);
+        for (int k = 0; k < 2; ++k) far[k] = nt_load4(in + (size_t)min(loaded + PV_TS + LB * k + lrow, H - 1) * rstride + ldd);
         if (u >= 0 && u < nT) {
-            lo = wave_min_i(lo == 0x7fffffff ? lo : lo - 4 * rt);
-            hi = wave_max_i(hi == -0x7fffffff ? hi : hi - 4 * rt);
-            f4 acc[4] = {zero4, zero4, zero4, zero4};
+            const int lo = wave_min_i(nn ? s0 : 0x7fffffff);
+            const int hi = wave_max_i(nn ? s0 + nn : -0x7fffffff);
+            f16v acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             if (hi > lo && !(dbg & 1)) {
                 const int K0 = lo & ~3; // multiple of 4 (two's complement floor), as R is: a 4-row read never wraps
                 const int n_it = (hi - K0 + 3) >> 2;
-                int tt[4];
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) tt[cc] = K0 + 4 * rt + dq - s[cc];
-                int sl = slot_rd + (K0 - y0) + 4 * rt; // K0 - y0 in [-usd - 15, 12]
+                int tt = K0 - s0;
+                int sl = slot_rd + (K0 - y0); // K0 - y0 in [-usd - 3, 15]
                 if (sl < 0) sl += R;
                 if (sl >= R) sl -= R;
-                const f4 *p = ring + sl * 16 + dd;
-                const f4 *const pend = ring + R * 16 + dd; // this lane's address one ring length on
-                f4 v0 = p[0], v1 = p[16], v2 = p[32], v3 = p[48];
-                f4 w0, w1, w2, w3;
-                // one iteration = 4 window rows: prefetch the next four rows into (N0..N3), mask VALU, 16 MFMAs on (C0..C3)
-#define STM_V_ITER(C0, C1, C2, C3, N0, N1, N2, N3)                                                          \
-    {                                                                                                       \
-        p += 64;                                                                                            \
-        if (p >= pend) p -= R * 16;                                                                         \
-        N0 = p[0]; N1 = p[16]; N2 = p[32]; N3 = p[48];                                                      \
-        const float m0 = ((unsigned)tt[0] < (unsigned)n[0]) ? 1.0f : 0.0f;                                  \
-        const float m1 = ((unsigned)tt[1] < (unsigned)n[1]) ? 1.0f : 0.0f;                                  \
-        const float m2 = ((unsigned)tt[2] < (unsigned)n[2]) ? 1.0f : 0.0f;                                  \
-        const float m3 = ((unsigned)tt[3] < (unsigned)n[3]) ? 1.0f : 0.0f;                                  \
-        tt[0] += 4; tt[1] += 4; tt[2] += 4; tt[3] += 4;                                                     \
-        acc[0] = STM_MFMA(m0, C0.x, acc[0], 0); acc[1] = STM_MFMA(m1, C0.y, acc[1], 0);                     \
-        acc[2] = STM_MFMA(m2, C0.z, acc[2], 0); acc[3] = STM_MFMA(m3, C0.w, acc[3], 0);                     \
-        acc[0] = STM_MFMA(m0, C1.x, acc[0], 1); acc[1] = STM_MFMA(m1, C1.y, acc[1], 1);                     \
-        acc[2] = STM_MFMA(m2, C1.z, acc[2], 1); acc[3] = STM_MFMA(m3, C1.w, acc[3], 1);                     \
-        acc[0] = STM_MFMA(m0, C2.x, acc[0], 2); acc[1] = STM_MFMA(m1, C2.y, acc[1], 2);                     \
-        acc[2] = STM_MFMA(m2, C2.z, acc[2], 2); acc[3] = STM_MFMA(m3, C2.w, acc[3], 2);                     \
-        acc[0] = STM_MFMA(m0, C3.x, acc[0], 3); acc[1] = STM_MFMA(m1, C3.y, acc[1], 3);                     \
-        acc[2] = STM_MFMA(m2, C3.z, acc[2], 3); acc[3] = STM_MFMA(m3, C3.w, acc[3], 3);                     \
-    }
-                for (int it = 0; it + 1 < n_it; it += 2) {
-                    STM_V_ITER(v0, v1, v2, v3, w0, w1, w2, w3)
-                    STM_V_ITER(w0, w1, w2, w3, v0, v1, v2, v3)
+                const float *p = ring + sl * 64 + l;
+                const float *const pend = ring + R * 64 + l; // this lane's address one ring length on
+                for (int it = 0; it < n_it; ++it) {
+                    const float c0 = p[0], c1 = p[64], c2 = p[128], c3 = p[192]; // four window rows
+                    p += 256;
+                    if (p >= pend) p -= R * 64;
+                    const float m0 = ((unsigned)tt < (unsigned)nn) ? 1.0f : 0.0f;
+                    const float m1 = ((unsigned)(tt + 1) < (unsigned)nn) ? 1.0f : 0.0f;
+                    const float m2 = ((unsigned)(tt + 2) < (unsigned)nn) ? 1.0f : 0.0f;
+                    const float m3 = ((unsigned)(tt + 3) < (unsigned)nn) ? 1.0f : 0.0f;
+                    tt += 4;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m0, c0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m1, c1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m2, c2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m3, c3, acc, 0, 0, 0);
                 }
-                if (n_it & 1) STM_V_ITER(v0, v1, v2, v3, w0, w1, w2, w3)
-#undef STM_V_ITER
             }
-            // register i of chain cc = out[row y0 + 4 rt + i][column 4 g + cc][hypothesis 16 c + dd]
-            int so = slot_wr + 4 * rt; // ring 2's slot of the output rows (first pass only)
+            // register 4b + i of lane 16q + n = out[row y0 + 4q + i][column 4g + b][hypothesis 16c + n]
+            int so = slot_wr + 4 * lb; // ring 2's slot of the lane's four output rows (first pass only)
             if (so >= R2) so -= R2;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int r = y0 + 4 * rt + i;
-                const f4 o = {acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+                const int r = y0 + 4 * lb + i;
                 if (r < H) {
-                    if (wv) nt_store4(out + (size_t)r * rstride + dd, o);
-                    else ring2[(so + i) * 16 + dd] = o;
+                    if (wv) {
+                        const f4 o = {acc[i], acc[4 + i], acc[8 + i], acc[12 + i]};
+                        nt_store4(out + (size_t)r * rstride + dd, o);
+                    } else {
+                        float *q = ring2 + (so + i) * 64 + dd;
+                        q[0] = acc[i]; q[16] = acc[4 + i]; q[32] = acc[8 + i]; q[48] = acc[12 + i];
+                    }
                 }
             }
             slot_rd += PV_TS;
@@ -428,12 +430,19 @@ __global__ __launch_bounds__(128 * NTP) void stm_k_pq_v12(PQViews v, int H, int 
             const int r = loaded + LB * k + lrow;
             int sw = slot_ld + LB * k + lrow;
             if (sw >= R1) sw -= R1;
-            if (r < H) ring1[sw * 16 + dd] = pre[k];
+            if (r < H) {
+                float *q = ring1 + sw * 64 + ldd;
+                q[0] = pre[k].x; q[16] = pre[k].y; q[32] = pre[k].z; q[48] = pre[k].w;
+            }
         }
+        pre[0] = far[0];
+        pre[1] = far[1];
+        STM_V_DECODE(u + NTP)
         loaded += PV_TS; // keeps advancing past H so that later steps load nothing
         slot_ld += PV_TS;
         if (slot_ld >= R1) slot_ld -= R1;
     }
+#undef STM_V_DECODE
 }
 
 // ------------------------------------------------------------------ launchers
@@ -461,31 +470,51 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
         STM_CHECK_LAUNCH();
     }
     constexpr int NW = 8;
-    const int HG = (usd + 3) / 4, NG = 4 * NW + 2 * HG; // halo groups: ceil(usd / 4) on either side of a segment
+    const int HG = (usd + 3) / 4 + 1, NG = 4 * NW + 2 * HG; // halo groups: ceil(usd / 4) on either side of a segment + 1 for the read-ahead
     const int nseg = cdiv(W, 16 * NW), nblk = ((nseg * H * 2 + 7) / 8) * 8;
     const size_t smem_h = (size_t)4 * NG * 256 + 16 * NW * 4;
+    const bool ntfill = (agg_variant() / 1000000) % 10 == 1;
     {
         ProfScope p("pq_h");
-        allow_lds_m((const void *)stm_k_pq_h<NW, false>, smem_h);
-        hipLaunchKernelGGL((stm_k_pq_h<NW, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
+        if (ntfill) {
+            allow_lds_m((const void *)stm_k_pq_h<NW, false, true>, smem_h);
+            hipLaunchKernelGGL((stm_k_pq_h<NW, false, true>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
+        } else {
+            allow_lds_m((const void *)stm_k_pq_h<NW, false, false>, smem_h);
+            hipLaunchKernelGGL((stm_k_pq_h<NW, false, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
+        }
         STM_CHECK_LAUNCH();
     }
     {
         ProfScope p("pq_v12");
-        constexpr int NTP = 3, TS = 16 * NTP;
+        const int ntp = (agg_variant() / 10000000) % 10 ? (agg_variant() / 10000000) % 10 : 3;
+        const int TS = 16 * ntp;
         const int R1 = (TS + 2 * usd + 3) & ~3;
         const int LAG = (usd > 1 ? (usd - 1 + TS - 1) / TS : 0) + 1; // the second pass may use first-pass rows of EARLIER steps only
         const int R2 = (TS * (LAG + 1) + usd + 3) & ~3;
         const size_t smem = (size_t)(R1 + R2) * 256;
-        allow_lds_m((const void *)stm_k_pq_v12<NTP>, smem);
-        hipLaunchKernelGGL(stm_k_pq_v12<NTP>, dim3(G, NC, 2), dim3(128 * NTP), smem, stream(), v, H, W, G, NC, usd, R1, R2, LAG,
-                           (agg_variant() / 100000) % 10);
+        const int dbg = (agg_variant() / 100000) % 10;
+#define STM_LAUNCH_V12(N)                                                                                                       \
+    {                                                                                                                           \
+        allow_lds_m((const void *)stm_k_pq_v12<N>, smem);                                                                       \
+        hipLaunchKernelGGL(stm_k_pq_v12<N>, dim3(G, NC, 2), dim3(128 * N), smem, stream(), v, H, W, G, NC, usd, R1, R2, LAG, dbg); \
+    }
+        if (ntp == 1) STM_LAUNCH_V12(1)
+        else if (ntp == 2) STM_LAUNCH_V12(2)
+        else if (ntp == 4) STM_LAUNCH_V12(4)
+        else STM_LAUNCH_V12(3)
+#undef STM_LAUNCH_V12
         STM_CHECK_LAUNCH();
     }
     {
         ProfScope p("pq_hw");
-        allow_lds_m((const void *)stm_k_pq_h<NW, true>, smem_h);
-        hipLaunchKernelGGL((stm_k_pq_h<NW, true>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
+        if (ntfill) {
+            allow_lds_m((const void *)stm_k_pq_h<NW, true, true>, smem_h);
+            hipLaunchKernelGGL((stm_k_pq_h<NW, true, true>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
+        } else {
+            allow_lds_m((const void *)stm_k_pq_h<NW, true, false>, smem_h);
+            hipLaunchKernelGGL((stm_k_pq_h<NW, true, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
+        }
         STM_CHECK_LAUNCH();
     }
 }
