@@ -4,8 +4,10 @@
 // are identical because the argument lists are identical.  Each function forwards to its stm_* C twin
 // (include/stm_hip.h), which documents semantics and cites the reference line by line.
 //
-// One signature differs on purpose: adcensus_stm takes `float angle` (the reference declares `int angle`,
-// d_io.h:36, silently truncating the float its only caller passes, video_io.cpp:158 -- SURVEY A-Q24).
+// All 33 reference names are exported with the reference's exact signatures (tests/test_abi.py holds the mangled names).
+// adcensus_stm / adcensus_stm_2 keep the reference's `int angle` (d_io.h:36,48): the float its only caller passes
+// (video_io.cpp:158) is truncated at the call site exactly as upstream (SURVEY A-Q24); adcensus_stm_f / adcensus_stm_2_f
+// are additions that keep the fractional angle.
 #ifndef STM_DROPIN_HPP
 #define STM_DROPIN_HPP
 
@@ -91,20 +93,33 @@ void d_mux_multiview(unsigned char** d_views, unsigned char* d_out_data, int num
                      int in_rows, int in_cols, int out_rows, int out_cols, int elem_sz);
 void mux_multiview(unsigned char** views, unsigned char* out_data, int num_views, float angle,
                    int in_rows, int in_cols, int out_rows, int out_cols, int elem_sz);
-// d_io.h:32-40 (angle: float, see header comment)
+// d_io.h:32-40.  `int angle` exactly as the reference declares it: a caller that passes a float (video_io.cpp:158 does) has
+// it truncated at the call site, as upstream (SURVEY A-Q24).  adcensus_stm_f keeps the fractional angle.
 void adcensus_stm(unsigned char* img_sbs, float* disp_l, float* disp_r, unsigned char* interlaced,
                   int num_rows, int num_cols_sbs, int num_cols,
                   int num_rows_out, int num_cols_out, int elem_sz,
-                  int num_views, float angle, int num_disp, int zero_disp,
+                  int num_views, int angle, int num_disp, int zero_disp,
                   float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
                   int thresh_s, float thresh_h);
-// d_io.h:42-52 (same `float angle` note as adcensus_stm)
-void adcensus_stm_2(unsigned char* img_sbs, float* disp_l, float* disp_r, unsigned char* interlaced,
-                    int num_rows, int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out,
-                    int num_rows_disp, int num_cols_disp, int elem_sz, float disp_scale,
+void adcensus_stm_f(unsigned char* img_sbs, float* disp_l, float* disp_r, unsigned char* interlaced,
+                    int num_rows, int num_cols_sbs, int num_cols,
+                    int num_rows_out, int num_cols_out, int elem_sz,
                     int num_views, float angle, int num_disp, int zero_disp,
                     float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
                     int thresh_s, float thresh_h);
+// d_io.h:42-52 (same `int angle`)
+void adcensus_stm_2(unsigned char* img_sbs, float* disp_l, float* disp_r, unsigned char* interlaced,
+                    int num_rows, int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out,
+                    int num_rows_disp, int num_cols_disp, int elem_sz, float disp_scale,
+                    int num_views, int angle, int num_disp, int zero_disp,
+                    float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
+                    int thresh_s, float thresh_h);
+void adcensus_stm_2_f(unsigned char* img_sbs, float* disp_l, float* disp_r, unsigned char* interlaced,
+                      int num_rows, int num_cols_sbs, int num_cols, int num_rows_out, int num_cols_out,
+                      int num_rows_disp, int num_cols_disp, int elem_sz, float disp_scale,
+                      int num_views, float angle, int num_disp, int zero_disp,
+                      float ad_coeff, float census_coeff, float ucd, float lcd, int usd, int lsd,
+                      int thresh_s, float thresh_h);
 // d_tx_scale.h:19-20 (host pointers, despite the prefix: d_tx_scale.cu:82-127)
 void d_tx_scale(unsigned char* in_data, unsigned char* out_data, int in_rows, int in_cols, int out_rows, int out_cols,
                 int elem_sz);

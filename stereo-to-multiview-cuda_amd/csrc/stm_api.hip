@@ -89,6 +89,7 @@ struct Arms {
 struct Dim { const char *name; int v, lo; };
 bool args_ok(const char *fn, std::initializer_list<Dim> dims)
 {
+    clear_failed(); // every entry point starts here: a failure is sticky for one API call only (stm_common.h)
     for (const Dim &d : dims)
         if (d.v < d.lo) {
             char msg[160];
@@ -584,6 +585,41 @@ void stm_d_demux_sbs(unsigned char *d_img_l, unsigned char *d_img_r, unsigned ch
 
 } // extern "C"
 
+// device staging buffers of the blocking host-flavour frame calls: grow-only, one set per host thread and device (the
+// reference's adcensus_stm allocates and frees them on every frame, d_io.cu:43-235)
+namespace {
+struct HostFrameBufs {
+    void *p[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap[4] = {0, 0, 0, 0};
+};
+thread_local HostFrameBufs g_hfb[16];
+// returns false (error recorded, nothing usable) if an allocation fails
+bool host_frame_bufs(const size_t (&bytes)[4], void *(&out)[4])
+{
+    HostFrameBufs &b = g_hfb[cur_dev() & 15];
+    for (int i = 0; i < 4; ++i) {
+        if (bytes[i] > b.cap[i]) {
+            if (b.p[i]) {
+                STM_CHECK(hipStreamSynchronize(stream()));
+                STM_CHECK(hipFree(b.p[i]));
+                b.p[i] = nullptr;
+                b.cap[i] = 0;
+            }
+            void *q = nullptr;
+            if (hipMalloc(&q, bytes[i]) != hipSuccess || !q) {
+                (void)hipGetLastError();
+                fail("adcensus_stm: device buffer allocation failed", "hipMalloc", __FILE__, __LINE__);
+                return false;
+            }
+            b.p[i] = q;
+            b.cap[i] = bytes[i];
+        }
+        out[i] = b.p[i];
+    }
+    return true;
+}
+} // namespace
+
 // =============================================================== whole frame
 // adcensus_stm, d_io.cu:7-238: demux -> cost init -> aggregation (L, R) -> WTA -> DCC -> IRV x5 ->
 // bilateral(7,5,10) -> hit maps -> bleed(1) -> masks -> N-2 synthesised views -> interlace.
@@ -602,7 +638,7 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
     const size_t HW = (size_t)H * W;
     const int NQ = (D + 3) / 4;
     const size_t V = HW * NQ * 4; // volumes are kept quad-interleaved (float4 [NQ][H][W]) inside the frame
-    const bool matrix_pipe = !hslo && (agg_variant() / 10000) % 10 != 1; // default aggregation path: stm_kernels_aggm.hip
+    const bool matrix_pipe = !hslo && (agg_variant() / 10000) % 10 != 1 && aggm_supports(usd); // default aggregation path: stm_kernels_aggm.hip
     float *cost = matrix_pipe ? nullptr : Workspace::get<float>(2 * V), *scratch = matrix_pipe ? nullptr : Workspace::get<float>(V);
     uint32_t *pk_l = pre ? pre[0] : Workspace::get<uint32_t>(HW), *pk_r = pre ? pre[1] : Workspace::get<uint32_t>(HW);
     Vol cl = vol_quads(cost, HW), cr = vol_quads(cost ? cost + V : nullptr, HW), sc = vol_quads(scratch, HW);
@@ -770,12 +806,11 @@ void stm_adcensus_stm_2(unsigned char *img_sbs, float *disp_l, float *disp_r, un
         return;
     size_t HW = (size_t)num_rows * num_cols, sbs_sz = (size_t)num_rows * num_cols_sbs * elem_sz;
     size_t out_sz = (size_t)num_rows_out * num_cols_out * elem_sz;
-    u8 *d_sbs, *d_out;
-    float *d_dl, *d_dr;
-    STM_CHECK(hipMalloc((void **)&d_sbs, sbs_sz));
-    STM_CHECK(hipMalloc((void **)&d_out, out_sz));
-    STM_CHECK(hipMalloc((void **)&d_dl, HW * 4));
-    STM_CHECK(hipMalloc((void **)&d_dr, HW * 4));
+    const size_t need[4] = {sbs_sz, out_sz, HW * 4, HW * 4};
+    void *buf[4];
+    if (!host_frame_bufs(need, buf)) return;
+    u8 *d_sbs = (u8 *)buf[0], *d_out = (u8 *)buf[1];
+    float *d_dl = (float *)buf[2], *d_dr = (float *)buf[3];
     STM_CHECK(hipMemcpyAsync(d_sbs, img_sbs, sbs_sz, hipMemcpyHostToDevice, stream()));
     STM_CHECK(hipMemsetAsync(d_out, 0, out_sz, stream()));
     stm_d_adcensus_stm_2(d_sbs, d_dl, d_dr, d_out, num_rows, num_cols_sbs, num_cols, num_rows_out, num_cols_out, num_rows_disp,
@@ -783,7 +818,6 @@ void stm_adcensus_stm_2(unsigned char *img_sbs, float *disp_l, float *disp_r, un
                          lcd, usd, lsd, thresh_s, thresh_h);
     down(disp_l, d_dl, HW); down(disp_r, d_dr, HW); down(interlaced, d_out, out_sz);
     sync();
-    STM_CHECK(hipFree(d_sbs)); STM_CHECK(hipFree(d_out)); STM_CHECK(hipFree(d_dl)); STM_CHECK(hipFree(d_dr));
 }
 
 // d_tx_scale.h:17-18  d_tx_scale (d_tx_scale.cu:83-121): despite the d_ prefix it takes HOST pointers
@@ -818,20 +852,18 @@ void stm_adcensus_stm(unsigned char *img_sbs, float *disp_l, float *disp_r, unsi
         return;
     size_t HW = (size_t)num_rows * num_cols, sbs_sz = (size_t)num_rows * num_cols_sbs * elem_sz;
     size_t out_sz = (size_t)num_rows_out * num_cols_out * elem_sz;
-    // own buffers come from plain hipMalloc: the pipeline call below re-carves the workspace
-    u8 *d_sbs, *d_out;
-    float *d_dl, *d_dr;
-    STM_CHECK(hipMalloc((void **)&d_sbs, sbs_sz));
-    STM_CHECK(hipMalloc((void **)&d_out, out_sz));
-    STM_CHECK(hipMalloc((void **)&d_dl, HW * 4));
-    STM_CHECK(hipMalloc((void **)&d_dr, HW * 4));
+    // own buffers are cached outside the workspace: the pipeline call below re-carves the workspace
+    const size_t need[4] = {sbs_sz, out_sz, HW * 4, HW * 4};
+    void *buf[4];
+    if (!host_frame_bufs(need, buf)) return;
+    u8 *d_sbs = (u8 *)buf[0], *d_out = (u8 *)buf[1];
+    float *d_dl = (float *)buf[2], *d_dr = (float *)buf[3];
     STM_CHECK(hipMemcpyAsync(d_sbs, img_sbs, sbs_sz, hipMemcpyHostToDevice, stream()));
     STM_CHECK(hipMemsetAsync(d_out, 0, out_sz, stream()));
     stm_d_adcensus_stm(d_sbs, d_dl, d_dr, d_out, num_rows, num_cols_sbs, num_cols, num_rows_out, num_cols_out, elem_sz,
                        num_views, angle, num_disp, zero_disp, ad_coeff, census_coeff, ucd, lcd, usd, lsd, thresh_s, thresh_h, 3);
     down(disp_l, d_dl, HW); down(disp_r, d_dr, HW); down(interlaced, d_out, out_sz);
     sync();
-    STM_CHECK(hipFree(d_sbs)); STM_CHECK(hipFree(d_out)); STM_CHECK(hipFree(d_dl)); STM_CHECK(hipFree(d_dr));
 }
 
 } // extern "C"

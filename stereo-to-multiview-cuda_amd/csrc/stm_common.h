@@ -11,6 +11,11 @@ namespace stm {
 
 // ---- error handling: reference semantics (cuda_utils.h:12-21) = message + exit(1) ----
 void fail(const char *what, const char *expr, const char *file, int line);
+// Error mode 1 (record and return, stm_set_error_mode): a failure is STICKY for the rest of the API call on this thread --
+// every later kernel launch of the call is skipped (STM_LAUNCH) and the workspace hands out no memory, so a failed
+// allocation can never turn into a kernel running on a null or stale pointer.  Each API entry point clears the flag.
+bool failed();
+void clear_failed();
 #define STM_CHECK(expr)                                                                  \
     do {                                                                                 \
         hipError_t _e = (expr);                                                          \
@@ -18,6 +23,10 @@ void fail(const char *what, const char *expr, const char *file, int line);
     } while (0)
 // the reference never checks launches; we do
 #define STM_CHECK_LAUNCH() STM_CHECK(hipGetLastError())
+#define STM_LAUNCH(...)                                     \
+    do {                                                    \
+        if (!::stm::failed()) hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
 
 hipStream_t stream();
 
@@ -41,6 +50,7 @@ struct ProfScope {
     ProfScope(const char *name);
     ~ProfScope();
     int slot;
+    void *ev_b; // end event (kept here: the record vector may be resized by another thread)
 };
 
 int agg_variant();
@@ -165,6 +175,7 @@ struct PQViews { // both views of a frame; a / b = the two PQ volumes of a view
     float *disp[2];
 };
 size_t pq_volume_floats(int D, int H, int W);
+bool aggm_supports(int usd);
 void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, const float *lut, float *const *vol_a, float *const *vol_b,
                        const u8 *const *armU, const u8 *const *armD, const u8 *const *armL, const u8 *const *armR, float *const *disp,
                        int D, int zd, int H, int W, int usd);
@@ -172,7 +183,6 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
 void launch_hslo_wta(int nviews, const Vol *cost, const u8 *const *img_a, const u8 *const *img_b, const int *osign,
                      float *const *disp, float *const *vol_out, float T, float H1, float H2, int D, int zd, int H, int W,
                      int elem_sz);
-void launch_scale_volume(Vol v, float s, int D, int H, int W);
 
 // host-built tables (same formulas as the reference's host code; see stm_tables.cpp)
 void rho_luts(float ad_coeff, float census_coeff, float *lut_ad /*766*/, float *lut_census /*65*/);

@@ -49,10 +49,16 @@ void d_mux_multiview(unsigned char** a, unsigned char* b, int c, float d, int e,
 void mux_multiview(unsigned char** a, unsigned char* b, int c, float d, int e, int f, int g, int h, int i)
 { stm_mux_multiview(a, b, c, d, e, f, g, h, i); }
 void adcensus_stm(unsigned char* a, float* b, float* c, unsigned char* d, int e, int f, int g, int h, int i, int j,
-                  int k, float l, int m, int n, float o, float p, float q, float r, int s, int t, int u, float v)
+                  int k, int l, int m, int n, float o, float p, float q, float r, int s, int t, int u, float v)
+{ stm_adcensus_stm(a, b, c, d, e, f, g, h, i, j, k, (float)l, m, n, o, p, q, r, s, t, u, v); }
+void adcensus_stm_f(unsigned char* a, float* b, float* c, unsigned char* d, int e, int f, int g, int h, int i, int j,
+                    int k, float l, int m, int n, float o, float p, float q, float r, int s, int t, int u, float v)
 { stm_adcensus_stm(a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, p, q, r, s, t, u, v); }
 void adcensus_stm_2(unsigned char* a, float* b, float* c, unsigned char* d, int e, int f, int g, int h, int i, int j, int k,
-                    int l, float m, int n, float o, int p, int q, float r, float s, float t, float u, int v, int w, int x, float y)
+                    int l, float m, int n, int o, int p, int q, float r, float s, float t, float u, int v, int w, int x, float y)
+{ stm_adcensus_stm_2(a, b, c, d, e, f, g, h, i, j, k, l, m, n, (float)o, p, q, r, s, t, u, v, w, x, y); }
+void adcensus_stm_2_f(unsigned char* a, float* b, float* c, unsigned char* d, int e, int f, int g, int h, int i, int j, int k,
+                      int l, float m, int n, float o, int p, int q, float r, float s, float t, float u, int v, int w, int x, float y)
 { stm_adcensus_stm_2(a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, p, q, r, s, t, u, v, w, x, y); }
 void d_tx_scale(unsigned char* a, unsigned char* b, int c, int d, int e, int f, int g) { stm_d_tx_scale(a, b, c, d, e, f, g); }
 void generateGaussianKernel(float* a, int b, float c) { stm_generate_gaussian_kernel(a, b, c); }

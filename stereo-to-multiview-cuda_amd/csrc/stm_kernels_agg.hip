@@ -121,7 +121,7 @@ void launch_cross_arms2(int nviews, const uint32_t *const *packed, u8 *const *up
             continue;
         }
         uint32_t *w = Workspace::get<uint32_t>((size_t)n);
-        hipLaunchKernelGGL(stm_k_widen_px, dim3(cdiv(n, 256)), dim3(256), 0, stream(), packed[v], w, n);
+        STM_LAUNCH(stm_k_widen_px, dim3(cdiv(n, 256)), dim3(256), 0, stream(), packed[v], w, n);
         STM_CHECK_LAUNCH();
         wide[v] = w;
     }
@@ -130,7 +130,7 @@ void launch_cross_arms2(int nviews, const uint32_t *const *packed, u8 *const *up
         a.img[v] = wide[s]; a.up[v] = up[s]; a.down[v] = down[s]; a.left[v] = left[s]; a.right[v] = right[s];
     }
     if (usd > 255) usd = 255; // arms are stored as u8 (reference T2)
-    hipLaunchKernelGGL(stm_k_cross_arms, dim3(cdiv(W, 256), H, nviews), dim3(256), 0, stream(), a, wide_threshold(ucd),
+    STM_LAUNCH(stm_k_cross_arms, dim3(cdiv(W, 256), H, nviews), dim3(256), 0, stream(), a, wide_threshold(ucd),
                        wide_threshold(lcd), usd, lsd, H, W);
     STM_CHECK_LAUNCH();
 }
@@ -340,7 +340,7 @@ static void launch_agg_h_tt(Vol in, Vol out, const u8 *armL, const u8 *armR, flo
     size_t smem = agg_h_smem(W, COST);
     allow_lds((const void *)stm_k_agg_h<QUAD, WTA, T, PPT, COST>, smem);
     AggHView none{in, out, armL, armR, disp, nullptr, nullptr, nullptr, nullptr, 0};
-    hipLaunchKernelGGL((stm_k_agg_h<QUAD, WTA, T, PPT, COST>), dim3(H, cdiv(nq, qpb), second ? 2 : 1), dim3(T), smem, stream(), in,
+    STM_LAUNCH((stm_k_agg_h<QUAD, WTA, T, PPT, COST>), dim3(H, cdiv(nq, qpb), second ? 2 : 1), dim3(T), smem, stream(), in,
                        out, armL, armR, disp, D, zd, H, W, qpb, first ? *first : none, second ? *second : none, lut);
     STM_CHECK_LAUNCH();
 }
@@ -517,7 +517,7 @@ static void launch_agg_v_t(Vol in, Vol out, const u8 *armU, const u8 *armD, int 
     const int nstrips = cdiv(W, TX), nb = cdiv(H, band);
     const int xcd_map = (agg_variant() / 1000) % 10 == 1 ? 0 : 1;
     const int ntiles8 = cdiv(nstrips * nb, 8) * 8;
-    hipLaunchKernelGGL((stm_k_agg_v<QUAD, TX, TY, OPT>), dim3((unsigned)ntiles8 * nq), dim3(TX, TY), smem, stream(), in, out,
+    STM_LAUNCH((stm_k_agg_v<QUAD, TX, TY, OPT>), dim3((unsigned)ntiles8 * nq), dim3(TX, TY), smem, stream(), in, out,
                        armU, armD, D, H, W, usd, R, band, nstrips, nb, nq, xcd_map);
     STM_CHECK_LAUNCH();
 }
@@ -573,7 +573,7 @@ void launch_wta(Vol cost, float *disp, int D, int zd, int H, int W)
 {
     size_t HW = (size_t)H * W;
     ProfScope p("wta");
-    hipLaunchKernelGGL(stm_k_wta, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream(), cost, disp, D, zd, HW);
+    STM_LAUNCH(stm_k_wta, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream(), cost, disp, D, zd, HW);
     STM_CHECK_LAUNCH();
 }
 

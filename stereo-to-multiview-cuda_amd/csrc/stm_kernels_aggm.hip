@@ -448,6 +448,18 @@ __global__ __launch_bounds__(128 * NTP) void stm_k_pq_v12(PQViews v, int H, int 
 // ------------------------------------------------------------------ launchers
 size_t pq_volume_floats(int D, int H, int W) { return (size_t)((D + 15) / 16) * H * ((W + 3) / 4) * 64; }
 
+// LDS of the fused vertical kernel: two rings of (48 + 2 usd) and (48 (LAG + 1) + usd) rows of 256 B
+static size_t v12_smem(int usd, int ntp)
+{
+    const int TS = 16 * ntp;
+    const int R1 = (TS + 2 * usd + 3) & ~3;
+    const int LAG = (usd > 1 ? (usd - 1 + TS - 1) / TS : 0) + 1;
+    const int R2 = (TS * (LAG + 1) + usd + 3) & ~3;
+    return (size_t)(R1 + R2) * 256;
+}
+// arms longer than this do not fit the CU's 160 KB: the caller falls back to the vector-ALU kernels (stm_kernels_agg.hip)
+bool aggm_supports(int usd) { return usd >= 1 && v12_smem(usd > 255 ? 255 : usd, 3) <= 160 * 1024; }
+
 // cost -> H -> V, V -> H + WTA for both views of a frame.  vol_a / vol_b: two PQ volumes per view (pq_volume_floats each).
 void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, const float *lut, float *const *vol_a, float *const *vol_b,
                        const u8 *const *armU, const u8 *const *armD, const u8 *const *armL, const u8 *const *armR, float *const *disp,
@@ -466,7 +478,7 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
         if (pad < 0) pad = 0;
         const size_t smem = (size_t)(2 * PC_TX + 2 * (PC_TX + 2 * pad) + 768 + 72) * 4;
         allow_lds_m((const void *)stm_k_pq_cost, smem);
-        hipLaunchKernelGGL(stm_k_pq_cost, dim3(cdiv(W, PC_TX), H, 2), dim3(PC_TX), smem, stream(), v, lut, D, zd, H, W, G, NC, pad);
+        STM_LAUNCH(stm_k_pq_cost, dim3(cdiv(W, PC_TX), H, 2), dim3(PC_TX), smem, stream(), v, lut, D, zd, H, W, G, NC, pad);
         STM_CHECK_LAUNCH();
     }
     constexpr int NW = 8;
@@ -478,10 +490,10 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
         ProfScope p("pq_h");
         if (ntfill) {
             allow_lds_m((const void *)stm_k_pq_h<NW, false, true>, smem_h);
-            hipLaunchKernelGGL((stm_k_pq_h<NW, false, true>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
+            STM_LAUNCH((stm_k_pq_h<NW, false, true>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
         } else {
             allow_lds_m((const void *)stm_k_pq_h<NW, false, false>, smem_h);
-            hipLaunchKernelGGL((stm_k_pq_h<NW, false, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
+            STM_LAUNCH((stm_k_pq_h<NW, false, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
         }
         STM_CHECK_LAUNCH();
     }
@@ -497,7 +509,7 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
 #define STM_LAUNCH_V12(N)                                                                                                       \
     {                                                                                                                           \
         allow_lds_m((const void *)stm_k_pq_v12<N>, smem);                                                                       \
-        hipLaunchKernelGGL(stm_k_pq_v12<N>, dim3(G, NC, 2), dim3(128 * N), smem, stream(), v, H, W, G, NC, usd, R1, R2, LAG, dbg); \
+        STM_LAUNCH(stm_k_pq_v12<N>, dim3(G, NC, 2), dim3(128 * N), smem, stream(), v, H, W, G, NC, usd, R1, R2, LAG, dbg); \
     }
         if (ntp == 1) STM_LAUNCH_V12(1)
         else if (ntp == 2) STM_LAUNCH_V12(2)
@@ -510,10 +522,10 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
         ProfScope p("pq_hw");
         if (ntfill) {
             allow_lds_m((const void *)stm_k_pq_h<NW, true, true>, smem_h);
-            hipLaunchKernelGGL((stm_k_pq_h<NW, true, true>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
+            STM_LAUNCH((stm_k_pq_h<NW, true, true>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
         } else {
             allow_lds_m((const void *)stm_k_pq_h<NW, true, false>, smem_h);
-            hipLaunchKernelGGL((stm_k_pq_h<NW, true, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
+            STM_LAUNCH((stm_k_pq_h<NW, true, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
         }
         STM_CHECK_LAUNCH();
     }

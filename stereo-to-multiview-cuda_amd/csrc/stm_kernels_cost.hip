@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void stm_k_pack_bgrx(const u8 *__restrict__ bg
 void launch_pack_bgrx(const u8 *bgr, uint32_t *packed, int H, int W, int elem_sz)
 {
     int n = H * W;
-    hipLaunchKernelGGL(stm_k_pack_bgrx, dim3(cdiv(n, 256)), dim3(256), 0, stream(), bgr, packed, n, elem_sz);
+    STM_LAUNCH(stm_k_pack_bgrx, dim3(cdiv(n, 256)), dim3(256), 0, stream(), bgr, packed, n, elem_sz);
     STM_CHECK_LAUNCH();
 }
 
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(CEN_TX *CEN_TY) void stm_k_census32(const uint32_t 
 // both images of a pair in one launch
 void launch_census32_pair(const uint32_t *packed_l, uint32_t *census_l, const uint32_t *packed_r, uint32_t *census_r, int H, int W)
 {
-    hipLaunchKernelGGL(stm_k_census32, dim3(cdiv(W, CEN_TX), cdiv(H, CEN_TY), 2), dim3(CEN_TX, CEN_TY), 0, stream(),
+    STM_LAUNCH(stm_k_census32, dim3(cdiv(W, CEN_TX), cdiv(H, CEN_TY), 2), dim3(CEN_TX, CEN_TY), 0, stream(),
                        packed_l, census_l, packed_r, census_r, H, W);
     STM_CHECK_LAUNCH();
 }
@@ -172,10 +172,10 @@ void launch_cost_init(const uint32_t *pk_l, const uint32_t *pk_r, const uint32_t
     size_t smem = (size_t)(4 * (CI_TX + 2 * pad) + 768 + 72) * 4;
     ProfScope p("cost_init");
     if (cost_l.quad)
-        hipLaunchKernelGGL(stm_k_cost_init<true>, dim3(cdiv(W, CI_TX), H), dim3(CI_TX), smem, stream(),
+        STM_LAUNCH(stm_k_cost_init<true>, dim3(cdiv(W, CI_TX), H), dim3(CI_TX), smem, stream(),
                            pk_l, pk_r, cen_l, cen_r, cost_l, cost_r, lut_ad, lut_census, D, zd, H, W, pad);
     else
-        hipLaunchKernelGGL(stm_k_cost_init<false>, dim3(cdiv(W, CI_TX), H), dim3(CI_TX), smem, stream(),
+        STM_LAUNCH(stm_k_cost_init<false>, dim3(cdiv(W, CI_TX), H), dim3(CI_TX), smem, stream(),
                            pk_l, pk_r, cen_l, cen_r, cost_l, cost_r, lut_ad, lut_census, D, zd, H, W, pad);
     STM_CHECK_LAUNCH();
 }

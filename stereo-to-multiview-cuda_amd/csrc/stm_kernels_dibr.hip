@@ -48,13 +48,13 @@ __global__ __launch_bounds__(256) void stm_k_demux_sbs_packed(u8 *__restrict__ l
 void launch_demux_sbs_packed(u8 *l, u8 *r, uint32_t *pk_l, uint32_t *pk_r, uint32_t *wide_l, uint32_t *wide_r, const u8 *sbs, int H,
                              int Wsbs, int W, int elem_sz)
 {
-    hipLaunchKernelGGL(stm_k_demux_sbs_packed, dim3(cdiv(2 * W, 256), H), dim3(256), 0, stream(), l, r, pk_l, pk_r, wide_l, wide_r,
+    STM_LAUNCH(stm_k_demux_sbs_packed, dim3(cdiv(2 * W, 256), H), dim3(256), 0, stream(), l, r, pk_l, pk_r, wide_l, wide_r,
                        sbs, Wsbs, W, elem_sz);
     STM_CHECK_LAUNCH();
 }
 void launch_demux_sbs(u8 *l, u8 *r, const u8 *sbs, int H, int Wsbs, int W, int elem_sz)
 {
-    hipLaunchKernelGGL(stm_k_demux_sbs, dim3(cdiv(Wsbs, 256), H), dim3(256), 0, stream(), l, r, sbs, H, Wsbs, W, elem_sz);
+    STM_LAUNCH(stm_k_demux_sbs, dim3(cdiv(Wsbs, 256), H), dim3(256), 0, stream(), l, r, sbs, H, Wsbs, W, elem_sz);
     STM_CHECK_LAUNCH();
 }
 
@@ -76,7 +76,7 @@ void launch_occl(u8 *occl_l, u8 *occl_r, const float *disp_l, const float *disp_
     size_t HW = (size_t)H * W;
     STM_CHECK(hipMemsetAsync(occl_l, 0, HW, stream())); // d_dibr_occl.cu:149-150
     STM_CHECK(hipMemsetAsync(occl_r, 0, HW, stream()));
-    hipLaunchKernelGGL(stm_k_occl, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), occl_l, occl_r, disp_l, disp_r, H, W);
+    STM_LAUNCH(stm_k_occl, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), occl_l, occl_r, disp_l, disp_r, H, W);
     STM_CHECK_LAUNCH();
 }
 
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void stm_k_bleed(const u8 *__restrict__ in, u8
 void launch_bleed(const u8 *in, u8 *out, int radius, int H, int W)
 {
     int ksz = (2 * radius + 1) * (2 * radius + 1);
-    hipLaunchKernelGGL(stm_k_bleed, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), in, out, radius, ksz, H, W);
+    STM_LAUNCH(stm_k_bleed, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), in, out, radius, ksz, H, W);
     STM_CHECK_LAUNCH();
 }
 
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void stm_k_median3(const float *__restrict__ i
 }
 void launch_median3(const float *in, float *out, int H, int W)
 {
-    hipLaunchKernelGGL(stm_k_median3, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), in, out, H, W);
+    STM_LAUNCH(stm_k_median3, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), in, out, H, W);
     STM_CHECK_LAUNCH();
 }
 
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void stm_k_occl_to_mask(float *__restrict__ ml
 void launch_occl_to_mask(float *mask_l, float *mask_r, const u8 *occl_l, const u8 *occl_r, int H, int W)
 {
     size_t HW = (size_t)H * W;
-    hipLaunchKernelGGL(stm_k_occl_to_mask, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream(), mask_l, mask_r, occl_l, occl_r, HW);
+    STM_LAUNCH(stm_k_occl_to_mask, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream(), mask_l, mask_r, occl_l, occl_r, HW);
     STM_CHECK_LAUNCH();
 }
 
@@ -219,7 +219,7 @@ void launch_hitmask_rows(float *mask_l, float *mask_r, const float *disp_l, cons
 {
     const size_t smem = 6 * (size_t)W;
     if (smem > 64 * 1024) STM_CHECK(hipFuncSetAttribute((const void *)stm_k_hitmask_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(stm_k_hitmask_rows, dim3(H), dim3(256), smem, stream(), mask_l, mask_r, disp_l, disp_r, H, W);
+    STM_LAUNCH(stm_k_hitmask_rows, dim3(H), dim3(256), smem, stream(), mask_l, mask_r, disp_l, disp_r, H, W);
     STM_CHECK_LAUNCH();
 }
 
@@ -262,7 +262,7 @@ void launch_view_synth(u8 *out, const u8 *img_l, const u8 *img_r, const float *d
     float shift_l = -shift;                               // d_dibr_bwarp.cu:56
     float shift_r = (float)(1.0 - (double)shift);         // :57
     ProfScope p("view_synth");
-    hipLaunchKernelGGL(stm_k_view_synth, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), out, img_l, img_r, disp_l, disp_r,
+    STM_LAUNCH(stm_k_view_synth, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), out, img_l, img_r, disp_l, disp_r,
                        mask_l, mask_r, blend, shift_l, shift_r, H, W, elem_sz);
     STM_CHECK_LAUNCH();
 }
@@ -312,7 +312,7 @@ void launch_view_synth_all(u8 *views, size_t view_stride, int N, const u8 *img_l
 {
     if (N < 3) return;
     ProfScope p("view_synth");
-    hipLaunchKernelGGL(stm_k_view_synth_all, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), views, view_stride, N, img_l, img_r,
+    STM_LAUNCH(stm_k_view_synth_all, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), views, view_stride, N, img_l, img_r,
                        disp_l, disp_r, mask_l, mask_r, blend, H, W, elem_sz);
     STM_CHECK_LAUNCH();
 }
@@ -346,9 +346,9 @@ __global__ __launch_bounds__(256) void stm_k_fwarp_copy(u8 *__restrict__ out, co
 void launch_fwarp(u8 *out, const u8 *img, const float *disp, float shift, unsigned long long *keys, int H, int W, int elem_sz)
 {
     STM_CHECK(hipMemsetAsync(keys, 0, (size_t)H * W * 8, stream()));
-    hipLaunchKernelGGL(stm_k_fwarp_vote, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), disp, shift, keys, H, W);
+    STM_LAUNCH(stm_k_fwarp_vote, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), disp, shift, keys, H, W);
     STM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(stm_k_fwarp_copy, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), out, img, keys, H, W, elem_sz);
+    STM_LAUNCH(stm_k_fwarp_copy, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), out, img, keys, H, W, elem_sz);
     STM_CHECK_LAUNCH();
 }
 
@@ -361,7 +361,7 @@ __global__ void stm_k_view_table(u8 **tab, u8 *first, u8 *last, u8 *mem, size_t 
 }
 void launch_view_table(u8 **tab, u8 *first, u8 *last, u8 *mem, size_t stride, int N)
 {
-    hipLaunchKernelGGL(stm_k_view_table, dim3(1), dim3(64 * ((N + 63) / 64)), 0, stream(), tab, first, last, mem, stride, N);
+    STM_LAUNCH(stm_k_view_table, dim3(1), dim3(64 * ((N + 63) / 64)), 0, stream(), tab, first, last, mem, stride, N);
     STM_CHECK_LAUNCH();
 }
 
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void stm_k_scale_bilinear(const u8 *__restrict
 }
 void launch_scale_bilinear(const u8 *in, u8 *out, int in_rows, int in_cols, int out_rows, int out_cols, int elem_sz)
 {
-    hipLaunchKernelGGL(stm_k_scale_bilinear, dim3(cdiv(out_cols, 256), out_rows), dim3(256), 0, stream(), in, out, in_rows,
+    STM_LAUNCH(stm_k_scale_bilinear, dim3(cdiv(out_cols, 256), out_rows), dim3(256), 0, stream(), in, out, in_rows,
                        in_cols, out_rows, out_cols, elem_sz);
     STM_CHECK_LAUNCH();
 }
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void stm_k_disp_scale(float *__restrict__ out,
 }
 void launch_disp_scale(float *out, const float *in, int out_rows, int out_cols, int in_rows, int in_cols, float disp_scale)
 {
-    hipLaunchKernelGGL(stm_k_disp_scale, dim3(cdiv(out_cols, 256), out_rows), dim3(256), 0, stream(), out, in, out_rows, out_cols,
+    STM_LAUNCH(stm_k_disp_scale, dim3(cdiv(out_cols, 256), out_rows), dim3(256), 0, stream(), out, in, out_rows, out_cols,
                        in_rows, in_cols, disp_scale);
     STM_CHECK_LAUNCH();
 }
@@ -474,7 +474,7 @@ void launch_mux(const u8 *const *d_views, u8 *out, int N, float y_interval, floa
                 int Win, int Hout, int Wout, int elem_sz, int variant)
 {
     ProfScope p("mux");
-    hipLaunchKernelGGL(stm_k_mux, dim3(cdiv(Wout, 256), Hout), dim3(256), 0, stream(), d_views, out, N, y_interval,
+    STM_LAUNCH(stm_k_mux, dim3(cdiv(Wout, 256), Hout), dim3(256), 0, stream(), d_views, out, N, y_interval,
                        inv_y_interval, ymod, Hin, Win, Hout, Wout, elem_sz, variant);
     STM_CHECK_LAUNCH();
 }

@@ -324,7 +324,7 @@ static void hslo_lines_launch(const HsloLineArgs &a, int nviews, float T, const 
     const size_t smem = per_wave * WPB * 4;
     if (smem > 64 * 1024)
         STM_CHECK(hipFuncSetAttribute((const void *)stm_k_hslo_lines<DPL, WPB, PERP, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL((stm_k_hslo_lines<DPL, WPB, PERP, CW>), dim3(cdiv(nlines, WPB), 2, nviews), dim3(64 * WPB), smem, stream(), a, T, P1[0],
+    STM_LAUNCH((stm_k_hslo_lines<DPL, WPB, PERP, CW>), dim3(cdiv(nlines, WPB), 2, nviews), dim3(64 * WPB), smem, stream(), a, T, P1[0],
                        P1[1], P1[2], P2[0], P2[1], P2[2], D, zd, nlines, len);
     STM_CHECK_LAUNCH();
 }
@@ -376,19 +376,19 @@ void launch_hslo_wta(int nviews, const Vol *cost, const u8 *const *img_a, const 
             continue;
         }
         float *planes = Workspace::get<float>(4 * HW);
-        hipLaunchKernelGGL(stm_k_hslo_avg, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), img_a[s], img_b[s], planes, planes + HW,
+        STM_LAUNCH(stm_k_hslo_avg, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), img_a[s], img_b[s], planes, planes + HW,
                            planes + 2 * HW, planes + 3 * HW, H, W, elem_sz);
         STM_CHECK_LAUNCH();
         const float4 *cq;
         if (cost[s].quad) cq = (const float4 *)cost[s].base;
         else {
             float4 *conv = Workspace::get<float4>(VQ);
-            hipLaunchKernelGGL(stm_k_to_quads, dim3((unsigned)((HW + 255) / 256), NQ), dim3(256), 0, stream(), cost[s], conv, D, HW);
+            STM_LAUNCH(stm_k_to_quads, dim3((unsigned)((HW + 255) / 256), NQ), dim3(256), 0, stream(), cost[s], conv, D, HW);
             STM_CHECK_LAUNCH();
             cq = conv;
         }
         float4 *ct = Workspace::get<float4>(VQ);
-        hipLaunchKernelGGL(stm_k_transpose_quads, dim3(cdiv(W, 32), cdiv(H, 32), NQ), dim3(256), 0, stream(), cq, ct, H, W);
+        STM_LAUNCH(stm_k_transpose_quads, dim3(cdiv(W, 32), cdiv(H, 32), NQ), dim3(256), 0, stream(), cq, ct, H, W);
         STM_CHECK_LAUNCH();
         float4 *oh = Workspace::get<float4>(2 * VQ), *ov = Workspace::get<float4>(2 * VQ);
         ah.cost[v] = cq; ah.out[v] = oh; ah.avg_a[v] = planes; ah.avg_b[v] = planes + HW;
@@ -397,33 +397,7 @@ void launch_hslo_wta(int nviews, const Vol *cost, const u8 *const *img_a, const 
     }
     hslo_lines<false>(ah, nviews, T, P1, P2, D, zd, H, W); // left->right and right->left
     hslo_lines<true>(av, nviews, T, P1, P2, D, zd, W, H);  // top->bottom and bottom->top on the transposed volume
-    hipLaunchKernelGGL(stm_k_hslo_combine_wta, dim3(cdiv(W, 32), cdiv(H, 32), nviews), dim3(256), 0, stream(), ac, D, zd, H, W);
-    STM_CHECK_LAUNCH();
-}
-
-// ------------------------------------------------------------------ misc volume op kept for the per-stage API
-__global__ __launch_bounds__(256) void stm_k_scale_volume(Vol v, float s, int D, size_t HW)
-{
-    size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
-    if (v.quad) {
-        for (int q = 0; q * 4 < D; ++q) {
-            float4 *a = (float4 *)v.base + (size_t)q * v.plane_stride + p;
-            float4 t = *a;
-            t.x = t.x * s; t.y = t.y * s; t.z = t.z * s; t.w = t.w * s;
-            *a = t;
-        }
-        return;
-    }
-    for (int d = 0; d < D; ++d) {
-        float *a = v.plane(d) + p;
-        *a = *a * s;
-    }
-}
-void launch_scale_volume(Vol v, float s, int D, int H, int W)
-{
-    size_t HW = (size_t)H * W;
-    hipLaunchKernelGGL(stm_k_scale_volume, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream(), v, s, D, HW);
+    STM_LAUNCH(stm_k_hslo_combine_wta, dim3(cdiv(W, 32), cdiv(H, 32), nviews), dim3(256), 0, stream(), ac, D, zd, H, W);
     STM_CHECK_LAUNCH();
 }
 

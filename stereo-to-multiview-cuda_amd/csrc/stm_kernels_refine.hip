@@ -9,6 +9,7 @@
 // All of them are image-sized (<= 17 B/px of HBM traffic) and LDS/latency bound; accumulation orders
 // follow the reference loops exactly (row-major taps, sequential float adds, no contraction).
 #include "stm_common.h"
+#include <mutex>
 
 #include <map>
 #include <utility>
@@ -50,10 +51,10 @@ void launch_dcc(u8 *out_l, u8 *out_r, const float *disp_l, const float *disp_r, 
     size_t HW = (size_t)H * W;
     STM_CHECK(hipMemsetAsync(hit_l, 1, HW, stream())); // d_dr_dcc.cu:107,111
     STM_CHECK(hipMemsetAsync(hit_r, 1, HW, stream()));
-    hipLaunchKernelGGL(stm_k_dcc_mark, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), out_l, out_r, disp_l, disp_r, hit_l,
+    STM_LAUNCH(stm_k_dcc_mark, dim3(cdiv(W, 256), H), dim3(256), 0, stream(), out_l, out_r, disp_l, disp_r, hit_l,
                        hit_r, H, W);
     STM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(stm_k_dcc_merge, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream(), out_l, out_r, hit_l,
+    STM_LAUNCH(stm_k_dcc_merge, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream(), out_l, out_r, hit_l,
                        hit_r, HW);
     STM_CHECK_LAUNCH();
 }
@@ -91,7 +92,7 @@ void launch_dcc_rows(u8 *out_l, u8 *out_r, const float *disp_l, const float *dis
 {
     const size_t smem = 4 * (size_t)W;
     if (smem > 64 * 1024) STM_CHECK(hipFuncSetAttribute((const void *)stm_k_dcc_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(stm_k_dcc_rows, dim3(H), dim3(256), smem, stream(), out_l, out_r, disp_l, disp_r, W);
+    STM_LAUNCH(stm_k_dcc_rows, dim3(H), dim3(256), smem, stream(), out_l, out_r, disp_l, disp_r, W);
     STM_CHECK_LAUNCH();
 }
 
@@ -347,7 +348,10 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
 {
     const size_t HW = (size_t)H * W;
     const int nb = D > 65 ? D : 65;
-    if (nviews < 1 || nviews > 2) fail("launch_irv: 1 or 2 views", "nviews", __FILE__, __LINE__);
+    if (nviews < 1 || nviews > 2) {
+        fail("launch_irv: 1 or 2 views", "nviews", __FILE__, __LINE__);
+        return; // only reached in error mode 1
+    }
     // host flavour (d_dr_irv.cu:344-353): one vote, then `iterations` applies of which only the first can change anything
     const int rounds = device_flavour ? iterations : (iterations > 0 ? 1 : 0);
     IrvArgs a;
@@ -375,12 +379,12 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
     }
     ProfScope p("irv");
     STM_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * ncount + 2 * dirty_sz, stream()));
-    hipLaunchKernelGGL(stm_k_irv_compact, dim3((unsigned)((HW + 4 * IC_T - 1) / (4 * IC_T)), nviews), dim3(IC_T), 0, stream(), a, (uint32_t)HW, zd,
+    STM_LAUNCH(stm_k_irv_compact, dim3((unsigned)((HW + 4 * IC_T - 1) / (4 * IC_T)), nviews), dim3(IC_T), 0, stream(), a, (uint32_t)HW, zd,
                        nb);
     STM_CHECK_LAUNCH();
     const size_t smem = (size_t)nb * IV_WAVES * 4;
     for (int it = 0; it < rounds; ++it) {
-        hipLaunchKernelGGL(stm_k_irv_vote, dim3(IV_BLOCKS, nviews), dim3(64 * IV_WAVES), smem, stream(), a, it, thresh_s, thresh_h, H,
+        STM_LAUNCH(stm_k_irv_vote, dim3(IV_BLOCKS, nviews), dim3(64 * IV_WAVES), smem, stream(), a, it, thresh_s, thresh_h, H,
                            W, nb, zd, usd, tiles_x, tiles_y);
         STM_CHECK_LAUNCH();
     }
@@ -565,7 +569,7 @@ void launch_bilateral(const float *in, float *out, const float *spatial, const f
 {
     if (radius == 7) {
         ProfScope p("bilateral");
-        hipLaunchKernelGGL(stm_k_bilateral_r<7>, dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY)), dim3(SF_TX, SF_TY), (size_t)D * 4, stream(),
+        STM_LAUNCH(stm_k_bilateral_r<7>, dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY)), dim3(SF_TX, SF_TY), (size_t)D * 4, stream(),
                            in, out, spatial, color, H, W, D);
         STM_CHECK_LAUNCH();
         return;
@@ -573,7 +577,7 @@ void launch_bilateral(const float *in, float *out, const float *spatial, const f
     int tw = ST_TX + 2 * radius, th = ST_TY + 2 * radius, kw = 2 * radius + 1;
     size_t smem = (size_t)(tw * th + kw * kw + D) * 4;
     ProfScope p("bilateral");
-    hipLaunchKernelGGL(stm_k_bilateral, dim3(cdiv(W, ST_TX), cdiv(H, ST_TY)), dim3(ST_TX, ST_TY), smem, stream(), in, out,
+    STM_LAUNCH(stm_k_bilateral, dim3(cdiv(W, ST_TX), cdiv(H, ST_TY)), dim3(ST_TX, ST_TY), smem, stream(), in, out,
                        spatial, color, radius, H, W, D);
     STM_CHECK_LAUNCH();
 }
@@ -619,23 +623,29 @@ void launch_gaussian_max(const float *in, float *out, const float *spatial, int 
 {
     if (radius == 10 || radius == 7) {
         static std::map<std::pair<int, float>, float> norms;
-        auto key = std::make_pair(radius, sigma);
-        auto it = norms.find(key);
-        if (it == norms.end()) it = norms.emplace(key, stencil_norm(radius, sigma)).first;
+        static std::mutex norms_mu; // first frames of two host threads may arrive together
+        float norm;
+        {
+            std::lock_guard<std::mutex> lock(norms_mu);
+            auto key = std::make_pair(radius, sigma);
+            auto it = norms.find(key);
+            if (it == norms.end()) it = norms.emplace(key, stencil_norm(radius, sigma)).first;
+            norm = it->second;
+        }
         ProfScope p("gaussian_max");
         if (radius == 10)
-            hipLaunchKernelGGL(stm_k_gaussian_max_r<10>, dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY)), dim3(SF_TX, SF_TY), 0, stream(), in,
-                               out, spatial, it->second, H, W, invert_input ? 1 : 0);
+            STM_LAUNCH(stm_k_gaussian_max_r<10>, dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY)), dim3(SF_TX, SF_TY), 0, stream(), in,
+                               out, spatial, norm, H, W, invert_input ? 1 : 0);
         else
-            hipLaunchKernelGGL(stm_k_gaussian_max_r<7>, dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY)), dim3(SF_TX, SF_TY), 0, stream(), in,
-                               out, spatial, it->second, H, W, invert_input ? 1 : 0);
+            STM_LAUNCH(stm_k_gaussian_max_r<7>, dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY)), dim3(SF_TX, SF_TY), 0, stream(), in,
+                               out, spatial, norm, H, W, invert_input ? 1 : 0);
         STM_CHECK_LAUNCH();
         return;
     }
     int tw = ST_TX + 2 * radius, th = ST_TY + 2 * radius, kw = 2 * radius + 1;
     size_t smem = (size_t)(tw * th + kw * kw) * 4;
     ProfScope p("gaussian_max");
-    hipLaunchKernelGGL(stm_k_gaussian_max, dim3(cdiv(W, ST_TX), cdiv(H, ST_TY)), dim3(ST_TX, ST_TY), smem, stream(), in, out,
+    STM_LAUNCH(stm_k_gaussian_max, dim3(cdiv(W, ST_TX), cdiv(H, ST_TY)), dim3(ST_TX, ST_TY), smem, stream(), in, out,
                        spatial, radius, H, W, invert_input ? 1 : 0);
     STM_CHECK_LAUNCH();
 }

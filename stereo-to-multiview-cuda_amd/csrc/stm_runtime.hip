@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -15,12 +16,16 @@ namespace stm {
 // ------------------------------------------------------------------ errors
 static int g_error_mode = 0;
 static thread_local std::string g_last_error;
+static thread_local bool g_failed = false;
+bool failed() { return g_failed; }
+void clear_failed() { g_failed = false; }
 
 void fail(const char *what, const char *expr, const char *file, int line)
 {
     char buf[1024];
     snprintf(buf, sizeof buf, "HIP error at: %s:%d\n%s %s", file, line, what, expr);
     g_last_error = buf;
+    g_failed = true;
     fprintf(stderr, "%s\n", buf);
     if (g_error_mode == 0)
         exit(1); // cuda_utils.h:15-20
@@ -77,28 +82,45 @@ void Workspace::begin(size_t hint)
 {
     WsState &w = ws();
     w.off = 0;
+    if (failed()) return;
     if (hint > w.cap) {
         // grow before carving so that one scope never straddles two slabs
         if (w.base) {
             STM_CHECK(hipStreamSynchronize(stream()));
             STM_CHECK(hipFree(w.base));
+            w.base = nullptr;
+            w.cap = 0;
         }
         size_t cap = hint + (hint >> 3) + (1u << 20);
-        STM_CHECK(hipMalloc((void **)&w.base, cap));
+        char *nb = nullptr;
+        if (hipMalloc((void **)&nb, cap) != hipSuccess || !nb) { // commit base / cap only after success
+            (void)hipGetLastError();
+            fail("workspace allocation failed", "hipMalloc", __FILE__, __LINE__);
+            return;
+        }
+        w.base = nb;
         w.cap = cap;
     }
 }
 
+// After a failure (error mode 1) every request is answered from a small static host buffer that no kernel will ever see:
+// launches are suppressed (STM_LAUNCH) and the copy calls that might receive it fail cleanly instead of faulting.
 void *Workspace::alloc(size_t bytes)
 {
+    static char sink[256];
     WsState &w = ws();
+    if (failed()) return sink;
     size_t a = (w.off + 255) & ~(size_t)255;
     if (a + bytes > w.cap) {
         // Late growth: earlier carve-outs of this scope live in the old slab and kernels
         // may be in flight on them, so retire (do not free) it until release.
         size_t cap = (a + bytes) * 2 + (1u << 20);
         char *nb = nullptr;
-        STM_CHECK(hipMalloc((void **)&nb, cap));
+        if (hipMalloc((void **)&nb, cap) != hipSuccess || !nb) {
+            (void)hipGetLastError();
+            fail("workspace allocation failed", "hipMalloc", __FILE__, __LINE__);
+            return sink;
+        }
         if (w.base) w.retired.push_back(w.base);
         w.base = nb;
         w.cap = cap;
@@ -128,12 +150,14 @@ static bool g_prof_on = false;
 bool prof_enabled() { return g_prof_on; }
 static std::vector<ProfRec> g_prof;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+static std::mutex g_prof_mu; // host threads may drive the library concurrently (stm_hip.h)
 
 ProfScope::ProfScope(const char *name) : slot(-1)
 {
     if (!g_prof_on) return;
     ProfRec r;
     r.name = name;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (!g_prof_pool.empty()) {
         r.a = g_prof_pool.back().first;
         r.b = g_prof_pool.back().second;
@@ -145,10 +169,11 @@ ProfScope::ProfScope(const char *name) : slot(-1)
     STM_CHECK(hipEventRecord(r.a, stream()));
     slot = (int)g_prof.size();
     g_prof.push_back(r);
+    ev_b = r.b;
 }
 ProfScope::~ProfScope()
 {
-    if (slot >= 0) STM_CHECK(hipEventRecord(g_prof[slot].b, stream()));
+    if (slot >= 0) STM_CHECK(hipEventRecord((hipEvent_t)ev_b, stream()));
 }
 
 static int g_agg_variant = 0;
@@ -220,6 +245,7 @@ void stm_release_workspace(void) { stm::ws_release(); }
 void stm_prof_enable(int on) { stm::g_prof_on = on != 0; }
 void stm_prof_reset(void)
 {
+    std::lock_guard<std::mutex> lock(stm::g_prof_mu);
     for (auto &r : stm::g_prof) stm::g_prof_pool.push_back({r.a, r.b});
     stm::g_prof.clear();
 }
@@ -227,6 +253,7 @@ int stm_prof_read(const char *kernel, float *total_ms)
 {
     int n = 0;
     float tot = 0.f;
+    std::lock_guard<std::mutex> lock(stm::g_prof_mu);
     for (auto &r : stm::g_prof) {
         if (r.name != kernel) continue;
         STM_CHECK(hipEventSynchronize(r.b));

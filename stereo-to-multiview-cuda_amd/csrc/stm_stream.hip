@@ -30,6 +30,7 @@ struct FrameStream {
     int H, Wsbs, W, Hout, Wout, E, N, D, zd, usd, lsd, thresh_s;
     float angle, ad, ce, ucd, lcd, thresh_h;
     size_t in_sz, out_sz, hw;
+    int dev = 0; // the device the stream was created on: submit / collect switch to it (and back) if the caller's differs
     hipStream_t s_in, s_compute, s_out;
     void *ws = nullptr;  // private workspace: addresses baked into the graphs stay valid
     bool use_graph = true;
@@ -52,6 +53,7 @@ void *stm_stream_create(int num_rows, int num_cols_sbs, int num_cols, int num_ro
     f->in_sz = (size_t)num_rows * num_cols_sbs * elem_sz;
     f->out_sz = (size_t)num_rows_out * num_cols_out * elem_sz;
     f->hw = (size_t)num_rows * num_cols;
+    STM_CHECK(hipGetDevice(&f->dev));
     STM_CHECK(hipStreamCreateWithFlags(&f->s_in, hipStreamNonBlocking));
     STM_CHECK(hipStreamCreateWithFlags(&f->s_compute, hipStreamNonBlocking));
     STM_CHECK(hipStreamCreateWithFlags(&f->s_out, hipStreamNonBlocking));
@@ -67,7 +69,7 @@ void *stm_stream_create(int num_rows, int num_cols_sbs, int num_cols, int num_ro
         STM_CHECK(hipMalloc((void **)&s.d_out, f->out_sz));
         STM_CHECK(hipMalloc((void **)&s.d_dl, f->hw * 4));
         STM_CHECK(hipMalloc((void **)&s.d_dr, f->hw * 4));
-        STM_CHECK(hipMemset(s.d_out, 0, f->out_sz));
+        STM_CHECK(hipMemsetAsync(s.d_out, 0, f->out_sz, f->s_compute)); // ordered before the first frame's writes
         STM_CHECK(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
         STM_CHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
         STM_CHECK(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
@@ -82,6 +84,10 @@ long stm_stream_submit(void *h, const unsigned char *img_sbs)
     FrameStream *f = (FrameStream *)h;
     Slot &s = f->slot[f->submitted & 1];
     if (s.busy) return -1;
+    stm::clear_failed();
+    int caller_dev = f->dev;
+    STM_CHECK(hipGetDevice(&caller_dev));
+    if (caller_dev != f->dev) STM_CHECK(hipSetDevice(f->dev));
     memcpy(s.h_in, img_sbs, f->in_sz); // the caller's buffer is free again when this returns (as with adcensus_stm)
     STM_CHECK(hipMemcpyAsync(s.d_in, s.h_in, f->in_sz, hipMemcpyHostToDevice, f->s_in));
     STM_CHECK(hipEventRecord(s.ev_in, f->s_in));
@@ -108,7 +114,16 @@ long stm_stream_submit(void *h, const unsigned char *img_sbs)
         hipGraph_t graph = nullptr;
         STM_CHECK(hipStreamBeginCapture(f->s_compute, hipStreamCaptureModeThreadLocal));
         pipeline();
-        STM_CHECK(hipStreamEndCapture(f->s_compute, &graph));
+        const bool capture_failed = stm::failed(); // error mode 1: something inside the capture recorded an error
+        STM_CHECK(hipStreamEndCapture(f->s_compute, &graph)); // always leave capture mode
+        if (capture_failed || !graph) {
+            if (graph) STM_CHECK(hipGraphDestroy(graph));
+            f->use_graph = false; // stay eager from now on
+            stm::ws_private_bind(nullptr);
+            stm_set_stream(prev);
+            if (caller_dev != f->dev) STM_CHECK(hipSetDevice(caller_dev));
+            return -1;
+        }
         STM_CHECK(hipGraphInstantiate(&s.gexec, graph, nullptr, nullptr, 0));
         STM_CHECK(hipGraphDestroy(graph));
         stm::ws_identity(&s.g_ws_base, &s.g_ws_cap);
@@ -125,6 +140,8 @@ long stm_stream_submit(void *h, const unsigned char *img_sbs)
     STM_CHECK(hipMemcpyAsync(s.h_dr, s.d_dr, f->hw * 4, hipMemcpyDeviceToHost, f->s_out));
     STM_CHECK(hipMemcpyAsync(s.h_out, s.d_out, f->out_sz, hipMemcpyDeviceToHost, f->s_out));
     STM_CHECK(hipEventRecord(s.ev_out, f->s_out));
+    if (caller_dev != f->dev) STM_CHECK(hipSetDevice(caller_dev));
+    if (stm::failed()) return -1; // error mode 1: the frame was not (completely) enqueued
     s.busy = true;
     return f->submitted++;
 }
