@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the MI355X-native stereo -> 8-view hot path.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
+  python bench.py --gpus N --steps K --warmup W
 
 A step = one synthetic 1080p side-by-side frame per rank through the device-resident frame pipeline
 (stm_d_adcensus_stm: cost init -> cross aggregation -> WTA -> DCC / IRV x5 / bilateral -> 6 DIBR views ->
@@ -9,11 +9,16 @@ interlacing).  Inputs are resident in HBM before the timed region.  Frames are i
 data-path collective (scaling = weak); the only communication is the RCCL broadcast of the input batch from
 rank 0 before timing starts.
 
+N > 1: one process per GPU.  Under `python -m torch.distributed.run` (RANK / WORLD_SIZE in the environment) this
+process is one of the ranks; started plainly (`python bench.py --gpus 8`) it launches torch.distributed.run itself as a
+CHILD process -- before anything here touches the GPU -- and exits with the child's code.
+
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,66 +29,89 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured with a float4 copy)
+AGG_KERNELS = ("pq_cost", "pq_h", "pq_v12", "pq_hw", "agg_h", "agg_v", "agg_hw", "cost_init")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--disp", type=int, default=64)
     ap.add_argument("--stages", type=int, default=3, help="1 = cost+agg+WTA (config 2), 2 = +refinement (config 3), 3 = full frame; add 256 for HSLO before WTA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--agg-variant", type=int, default=0)
+    ap.add_argument("--agg-variant", type=int, default=0, help="0 = matrix-pipe aggregation (default), 10000 = vector-ALU kernels")
     return ap.parse_args()
 
 
-def cpu_baseline(sbs, p, H, W, D, zd):
-    """The oracle (CPU restatement of the reference, kind 'port') timed on the host cores on a bounded sample of the
-    same workload: the full pipeline on the top quarter-height strip of the same frame; if that took under 3 s (many
-    cores) the whole frame is timed instead.  Scaled to whole frames per second."""
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child job (nothing in THIS process
+    has initialised the GPU) and hand its exit code back."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline_and_parity(sbs, p, H, W, D, zd, stages, run_gpu):
+    """The oracle (CPU restatement of the reference, kind 'port') timed on the host cores on a bounded sample of the same
+    workload -- the whole frame when the host has the cores for it (about 3 s on 128 threads), otherwise the top
+    quarter-height strip -- and, in the same run, the parity check SURVEY 8d asks for: the HIP pipeline is run on exactly
+    that sample and every output is compared with the oracle's, element by element."""
     from oracle import pyoracle as orc
     orc.build()
+    hslo = bool(stages & 0x100)
 
     def run(rows):
         part = np.ascontiguousarray(sbs[:rows])
         t0 = time.perf_counter()
-        orc.adcensus_stm(part, rows, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd, p.usd,
-                         p.lsd, p.thresh_s, p.thresh_h)
-        return time.perf_counter() - t0
+        want = orc.adcensus_stm(part, rows, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd, p.usd,
+                                p.lsd, p.thresh_s, p.thresh_h, hslo=hslo)
+        return time.perf_counter() - t0, part, want
 
-    rows = max(H // 4, 64)
-    dt = run(rows)
-    if dt < 3.0 and rows < H:
-        rows = H
-        dt = run(rows)
+    rows = max(H // 4, 64) if orc.num_threads() < 32 else H
+    rows = min(rows, H)
+    dt, part, want = run(rows)
     fps = (1.0 / dt) * (rows / float(H))
-    return {"value": fps, "unit": "frames/s", "cores": orc.num_threads(), "kind": "port",
+    base = {"value": fps, "unit": "frames/s", "cores": orc.num_threads(), "kind": "port",
             "sample": "full pipeline (oracle/stm_oracle.c, OpenMP) on the top %dx%d rows of the same frame, D=%d: %.1f s wall x %d "
                       "threads; scaled by %d/%d to whole frames" % (W, rows, D, dt, orc.num_threads(), rows, H)}
+    dl, dr, out = run_gpu(part, rows)
+    s = stages & 0xff
+    wl, wr = (want["wta_l"], want["wta_r"]) if s == 1 else (want["disp_l"], want["disp_r"])
+    parity = {"disp_l_mismatch": int((dl != wl).sum()), "disp_r_mismatch": int((dr != wr).sum()),
+              "interlaced_mismatch": int((out != want["interlaced"]).sum()) if s == 3 else None,
+              "compared": "%dx%d rows of the benchmarked frame, HIP pipeline vs oracle, every element" % (W, rows)}
+    return base, parity
 
 
 def main():
     args = parse()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world_env == 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
     import torch
     import torch.distributed as dist
     import stm_amd
     from stm_amd import device_api as dev, sharding, synth
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = world_env
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     stm_amd.lib()  # raises if the HIP library is missing: there is no fallback path
     torch.cuda.set_device(local_rank)
+    rccl_world = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        rccl_world = dist.get_world_size()
 
     H, W, D = args.height, args.width, args.disp
     zd = D // 2
@@ -117,57 +145,69 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n, profile):
+        barrier()
+        if profile:
+            dev.prof_reset()
+            dev.prof_enable(True)  # HIP events around the named kernels, on the launch stream, inside the timed region
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if profile:
+            dev.prof_enable(False)
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         step()
-    barrier()
-    dev.prof_reset()
-    dev.prof_enable(True)  # HIP events around the named kernels, on the launch stream, inside the timed region
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    dev.prof_enable(False)
-
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = timed(args.steps, True)
+    kern = {}
+    if rank == 0:
+        for name in AGG_KERNELS + ("cross_arms", "hslo", "wta", "irv", "bilateral", "gaussian_max", "view_synth", "mux"):
+            n, ms = dev.prof_read(name)
+            if n:
+                kern[name] = {"launches": n, "avg_ms": ms / n, "total_ms": ms}
+    # "wall-clock over >= 100 frames": when the driver asks for fewer steps, a second, un-profiled loop gives it
+    n100 = max(100, args.steps)
+    dt100 = timed(n100, False) if args.steps < 100 else dt
 
     if rank == 0:
         V = float(D) * H * W * 4
         HW = float(H) * W
-        # algorithmic bytes per launch: one un-fused pass over one view = 2V + 2HW;
-        # last pass fused with WTA = V + 2HW (arms) + 4HW (disparity out)
-        # The frame pipeline launches the first H pass and the fused H + WTA pass once for BOTH views (with HSLO the
-        # four passes run per view and there is no fused WTA pass); the V passes are always one view per launch.
-        # Without HSLO that first H pass also computes the initial costs on the fly: per view it reads four dword planes
-        # (BGRX + census of both images) and the two arm planes and writes V.
+        # algorithmic bytes per launch (compulsory inputs + outputs, each buffer once).  The matrix-pipe kernels
+        # serve BOTH views per launch: pq_cost writes 2 V from 4 dword planes per view; pq_h reads and writes a volume per
+        # view (+ 2 arm planes); pq_v12 = both vertical passes fused (K2 of SURVEY 8d): V in, V out, 2 arm planes per view;
+        # pq_hw = last pass + WTA: V in, 2 arm planes, disparity out.  Vector-ALU kernels (--agg-variant 10000): as round 1.
         hslo = bool(args.stages & 0x100)
-        alg = {"agg_h": (2 * V + 2 * HW) if hslo else 2 * (V + 2 * HW + 16 * HW), "agg_v": 2 * V + 2 * HW,
+        alg = {"pq_cost": 2 * V + 16 * HW, "pq_h": 2 * (2 * V + 2 * HW), "pq_v12": 2 * (2 * V + 2 * HW), "pq_hw": 2 * (V + 6 * HW),
+               "agg_h": (2 * V + 2 * HW) if hslo else 2 * (V + 2 * HW + 16 * HW), "agg_v": 2 * V + 2 * HW,
                "agg_hw": 2 * (V + 2 * HW + 4 * HW), "cost_init": 2 * V + 4 * 4 * HW}
-        kern = {}
-        for name in ["agg_h", "agg_v", "agg_hw", "cost_init", "cross_arms", "hslo", "wta", "irv", "bilateral", "gaussian_max",
-                     "view_synth", "mux"]:
-            n, ms = dev.prof_read(name)
-            if n:
-                kern[name] = {"launches": n, "avg_ms": ms / n, "total_ms": ms}
-        dom = max([k for k in ("agg_h", "agg_v", "agg_hw") if k in kern], key=lambda k: kern[k]["total_ms"])
-        achieved = alg[dom] / (kern[dom]["avg_ms"] * 1e-3) / 1e9
-        agg_total_ms = sum(kern[k]["total_ms"] for k in ("agg_h", "agg_v", "agg_hw") if k in kern) / args.steps
-        agg_bytes = sum(alg[k] * kern[k]["launches"] for k in ("agg_h", "agg_v", "agg_hw") if k in kern) / args.steps
-        # HBM bytes per launch from the PMC counters (FETCH_SIZE/WRITE_SIZE need their own rocprofv3 --pmc passes, so they
-        # cannot be sampled inside this process): taken from the committed summary of the same workload, or null
-        traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tj) and (H, W, D) == (1080, 1920, 64):
-            t = json.load(open(tj))
-            if dom in t:
-                traffic, traffic_src = t[dom]["traffic_bytes"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)"
-        roofline = {"bound": "hbm", "kernel": "stm_k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kern[dom]["avg_ms"],
-                    "agg_stage_ms_per_frame": agg_total_ms, "agg_stage_GBps": agg_bytes / (agg_total_ms * 1e-3) / 1e9}
+        traffic_all, traffic_src = {}, None
+        tj = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(tj) and (H, W, D, args.agg_variant, args.stages) == (1080, 1920, 64, 0, 3):
+            traffic_all = json.load(open(tj))
+            traffic_src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 per MI355X_MICROARCH.md)"
+        per_kernel = {}
+        for k in AGG_KERNELS:
+            if k in kern:
+                ach = alg[k] / (kern[k]["avg_ms"] * 1e-3) / 1e9
+                per_kernel[k] = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": kern[k]["avg_ms"],
+                                 "launches_per_frame": kern[k]["launches"] / float(args.steps), "algorithmic_bytes_per_launch": alg[k],
+                                 "traffic": traffic_all.get(k, {}).get("traffic_bytes")}
+        agg_names = [k for k in per_kernel if k not in ("pq_cost", "cost_init")]
+        dom = max(agg_names, key=lambda k: kern[k]["total_ms"])
+        stage_ms = sum(kern[k]["total_ms"] for k in per_kernel) / args.steps
+        stage_bytes = sum(alg[k] * kern[k]["launches"] for k in per_kernel) / args.steps
+        roofline = {"bound": "hbm", "kernel": "stm_k_" + dom, "achieved": per_kernel[dom]["achieved"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": per_kernel[dom]["traffic"],
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg[dom],
+                    "avg_launch_ms": kern[dom]["avg_ms"], "kernels": per_kernel,
+                    "agg_stage_ms_per_frame": stage_ms, "agg_stage_GBps": stage_bytes / (stage_ms * 1e-3) / 1e9,
+                    "agg_stage_frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         fps = world * args.steps / dt
         res = {
             "metric": "stereo->8-view frames/sec @1080p d=64; cost-agg HBM GB/s vs roofline",
@@ -179,12 +219,23 @@ def main():
                               2: "config 2 + DCC + IRV x5 + bilateral (config 3)",
                               3: "full stereo->8-view frame: cost init + cross aggregation + WTA + DCC/IRV x5/bilateral + 6 DIBR views + interlacing"}[args.stages & 0xff]
                 + (" + scanline optimisation (HSLO) before WTA" if args.stages & 0x100 else "")),
-                       "stages": args.stages, "usd": p.usd, "lsd": p.lsd, "views": p.num_views, "sharding": "frames, 1 per rank"},
+                       "stages": args.stages, "usd": p.usd, "lsd": p.lsd, "views": p.num_views, "sharding": "frames, 1 per rank",
+                       "aggregation": "matrix pipe (stm_kernels_aggm.hip)" if args.agg_variant == 0 else "agg_variant %d" % args.agg_variant},
+            "rccl_world_size": rccl_world,
+            "rate_over_100_frames": {"frames": n100, "frames_per_s": world * n100 / dt100, "ms_per_frame": dt100 / n100 * 1e3},
             "roofline": roofline,
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern.items()},
         }
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(sbs_host, p, H, W, D, zd)
+            def run_gpu(part, rows):
+                d_part = torch.from_numpy(part).cuda()
+                a = torch.zeros(rows, W, dtype=torch.float32, device="cuda")
+                b = torch.zeros_like(a)
+                o = torch.zeros(rows, W, 3, dtype=torch.uint8, device="cuda")
+                dev.d_adcensus_stm(d_part, a, b, o, p, stages=args.stages)
+                torch.cuda.synchronize()
+                return a.cpu().numpy(), b.cpu().numpy(), o.cpu().numpy()
+            res["cpu_baseline"], res["parity"] = cpu_baseline_and_parity(sbs_host, p, H, W, D, zd, args.stages, run_gpu)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

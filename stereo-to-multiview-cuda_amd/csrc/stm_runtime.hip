@@ -22,6 +22,7 @@ void clear_failed() { g_failed = false; }
 
 void fail(const char *what, const char *expr, const char *file, int line)
 {
+    if (g_failed && g_error_mode != 0) return; // the first error of an API call is the cause; the rest are its echoes
     char buf[1024];
     snprintf(buf, sizeof buf, "HIP error at: %s:%d\n%s %s", file, line, what, expr);
     g_last_error = buf;

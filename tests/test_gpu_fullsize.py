@@ -211,3 +211,56 @@ def test_two_host_threads_first_frames_together(gpu_ready, orc, stm):
         want = _oracle(orc, frames[i], p, H, W, D, zd)
         dl, dr, out = results[i]
         assert np.array_equal(dl, want["disp_l"]) and np.array_equal(dr, want["disp_r"]) and np.array_equal(out, want["interlaced"])
+
+
+# ----------------------------------------------------------------------------- BASELINE config 1 at its real size
+@pytest.fixture(scope="module")
+def c1():
+    import os
+    from conftest import GOLDEN
+    from stm_amd import bmp_io
+    g = dict(np.load(os.path.join(GOLDEN, "bud_c1_golden.npz")))
+    L, R = bmp_io.read_bmp(os.path.join(GOLDEN, "bud_2.bmp")), bmp_io.read_bmp(os.path.join(GOLDEN, "bud_3.bmp"))
+    D, zd, ad, ce, ucd, lcd, usd, lsd, ts, th, N, angle = [float(x) for x in g["params"]]
+    return g, L, R, dict(D=int(D), zd=int(zd), ad=ad, ce=ce, ucd=ucd, lcd=lcd, usd=int(usd), lsd=int(lsd), ts=int(ts), th=th, N=int(N), angle=angle)
+
+
+def test_c1_bud_pair_through_adcensus_stm(gpu_ready, c1):
+    """The reference's own img/bud_2 + img/bud_3 pair (640x384, D=32, 8 views) through the blocking host entry point
+    stm_adcensus_stm (adcensus_stm, d_io.cu:7-238), against the committed oracle vectors."""
+    from stm_amd import host_api as api
+    g, L, R, p = c1
+    sbs = np.ascontiguousarray(np.concatenate([L, R], axis=1))
+    dl, dr, out = api.adcensus_stm(sbs, 640, 384, 640, p["N"], p["angle"], p["D"], p["zd"], p["ad"], p["ce"], p["ucd"], p["lcd"],
+                                   p["usd"], p["lsd"], p["ts"], p["th"])
+    assert np.array_equal(dl, g["frame_disp_l"]) and np.array_equal(dr, g["frame_disp_r"])
+    assert np.array_equal(out, g["frame_mux"])
+
+
+def test_c1_bud_pair_through_the_image_io_stage_chain(gpu_ready, c1):
+    """The same pair through the per-stage HOST API in the still-image driver's order and constants (image_io.cpp:171-292:
+    IRV x1, bilateral 7/7/7, host-flavour dibr_dbm), every stage output against the committed oracle vectors."""
+    from stm_amd import host_api as api
+    g, L, R, p = c1
+    D, zd, N = p["D"], p["zd"], p["N"]
+    cl, cr = api.ci_adcensus(L, R, p["ad"], p["ce"], D, zd)
+    xl, al = api.ca_cross(L, cl, p["ucd"], p["lcd"], p["usd"], p["lsd"])
+    xr, ar = api.ca_cross(R, cr, p["ucd"], p["lcd"], p["usd"], p["lsd"])
+    dl, dr = api.dc_wta(al, zd), api.dc_wta(ar, zd)
+    assert np.array_equal(xl, g["chain_cross_l"]) and np.array_equal(dl, g["chain_wta_l"].astype(np.float32))
+    ol, orr = api.dr_dcc(dl, dr)
+    assert np.array_equal(ol, g["chain_outl_l"])
+    dl, ol = api.dr_irv(dl, ol, xl, p["ts"], p["th"], D, zd, p["usd"], 1)
+    dr, orr = api.dr_irv(dr, orr, xr, p["ts"], p["th"], D, zd, p["usd"], 1)
+    dl, dr = api.filter_bilateral_1(dl, 7, 7.0, 7.0, D), api.filter_bilateral_1(dr, 7, 7.0, 7.0, D)
+    assert np.array_equal(dl, g["chain_disp_l"]) and np.array_equal(dr, g["chain_disp_r"])
+    occl_l, occl_r = api.dibr_occl(dl, dr)
+    occl_l, occl_r = api.filter_bleed_1(occl_l, 1), api.filter_bleed_1(occl_r, 1)
+    ml, mr = api.dibr_occl_to_mask(occl_l, occl_r)
+    views = [R]
+    for v in range(1, N - 1):
+        shift = float(np.float32(1.0 - (1.0 * np.float32(v)) / (np.float32(N) - 1.0)))
+        views.append(api.dibr_dbm(L, R, dl, dr, occl_l, occl_r, ml, mr, shift))
+    views.append(L)
+    assert np.array_equal(views[3], g["chain_view_3"])
+    assert np.array_equal(api.mux_multiview(views, p["angle"], 384, 640), g["chain_mux"])

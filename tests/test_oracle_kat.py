@@ -242,3 +242,24 @@ def test_generate_gaussian_kernel_matches_oracle_table(orc, stm):
         k = np.zeros((2 * r + 1) ** 2, np.float32)
         stm.lib().stm_generate_gaussian_kernel(k.ctypes.data_as(C.POINTER(C.c_float)), r, s)
         assert np.array_equal(k, orc.gaussian_kernel_2d(r, s).ravel())
+
+
+def test_c1_full_size_golden_regression(orc):
+    """BASELINE config 1 at its real size (bud_2 + bud_3, 640x384, D=32, 8 views): the oracle keeps reproducing the
+    committed vectors of tests/golden/make_golden_c1.py, and the pair's statistics match SURVEY 8c's independent check
+    (background plateau at offset -6 for about half of the pixels, about 14 % L/R outliers)."""
+    import os
+    from conftest import GOLDEN
+    from stm_amd import bmp_io
+    g = dict(np.load(os.path.join(GOLDEN, "bud_c1_golden.npz")))
+    L, R = bmp_io.read_bmp(os.path.join(GOLDEN, "bud_2.bmp")), bmp_io.read_bmp(os.path.join(GOLDEN, "bud_3.bmp"))
+    assert L.shape == (384, 640, 3) and R.shape == (384, 640, 3)
+    D, zd, ad, ce, ucd, lcd, usd, lsd, ts, th, N, angle = [float(x) for x in g["params"]]
+    D, zd, usd, lsd, ts, N = int(D), int(zd), int(usd), int(lsd), int(ts), int(N)
+    sbs = np.ascontiguousarray(np.concatenate([L, R], axis=1))
+    fr = orc.adcensus_stm(sbs, 384, 640, N, angle, D, zd, ad, ce, ucd, lcd, usd, lsd, ts, th)
+    assert np.array_equal(fr["wta_l"], g["frame_wta_l"].astype(np.float32)) and np.array_equal(fr["wta_r"], g["frame_wta_r"].astype(np.float32))
+    assert np.array_equal(fr["disp_l"], g["frame_disp_l"]) and np.array_equal(fr["disp_r"], g["frame_disp_r"])
+    assert np.array_equal(fr["interlaced"], g["frame_mux"])
+    mode, share, outl = g["stats"]
+    assert mode == -6 and 0.45 < share < 0.58 and 0.10 < outl < 0.20

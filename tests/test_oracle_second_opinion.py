@@ -233,3 +233,179 @@ def test_wta_and_dcc_second_opinion(orc):
     want_l = np.where(bad_l, np.where(hit_l == 1, 2, 1), 0).astype(np.uint8)
     want_r = np.where(bad_r, np.where(hit_r == 1, 2, 1), 0).astype(np.uint8)
     assert np.array_equal(ol, want_l) and np.array_equal(orr, want_r)
+
+
+# ------------------------------------------------------------------------------------------------ HSLO (a14)
+def _hslo_py(cost, img_l, img_r, T, H1, H2, zd):
+    """Mei et al. section 3.3 as DESIGN.md section 2 fixes it: four scan directions; along direction r
+    Cr(p,d) = C(p,d) + min(Cr(p-r,d), Cr(p-r,d+-1) + P1, min_k Cr(p-r,k) + P2) - min_k Cr(p-r,k); the first pixel of a line
+    takes C(p,d); (P1, P2) from the colour steps D1 (own image, integer mean of B,G,R) and D2 (other image at the matched
+    pixel x + (d - zd), clamped; float mean): both < T -> (H1, H2); exactly one strictly on each side -> / 4; else / 10.
+    Final cost = mean of the four directions; WTA with the first strictly-lowest rule.  float64 throughout."""
+    D, H, W = cost.shape
+    c = cost.astype(np.float64)
+    mean_l = (img_l.astype(np.int64).sum(axis=2) // 3).astype(np.float64)            # u8 integer average
+    # the other image's mean is a float32 value ((float)(sum / 3.0)) and so is the difference of two of them: at D2 == T the
+    # class depends on that rounding, so it is part of the stage's definition
+    mean_r = (img_r.astype(np.int64).sum(axis=2).astype(np.float64) / 3.0).astype(np.float32)
+    total = np.zeros_like(c)
+    for (dx, dy) in [(1, 0), (-1, 0), (0, 1), (0, -1)]:
+        acc = np.zeros_like(c)
+        lines = range(H) if dx else range(W)
+        n = W if dx else H
+        for line in lines:
+            prev = None
+            for i in range(n):
+                if dx:
+                    y, x = line, (i if dx > 0 else W - 1 - i)
+                else:
+                    x, y = line, (i if dy > 0 else H - 1 - i)
+                if prev is None:
+                    cur = c[:, y, x].copy()
+                else:
+                    px, py = x - dx, y - dy
+                    m = prev.min()
+                    D1 = abs(mean_l[y, x] - mean_l[py, px])
+                    cur = np.empty(D)
+                    for d in range(D):
+                        o = d - zd
+                        qx, qpx = min(max(x + o, 0), W - 1), min(max(px + o, 0), W - 1)
+                        D2 = float(np.abs(np.float32(mean_r[y, qx] - mean_r[py, qpx])))
+                        if D1 < T and D2 < T:
+                            P1, P2 = H1, H2
+                        elif (D1 < T and D2 > T) or (D1 > T and D2 < T):
+                            P1, P2 = H1 / 4.0, H2 / 4.0
+                        else:
+                            P1, P2 = H1 / 10.0, H2 / 10.0
+                        best = prev[d]
+                        if d > 0:
+                            best = min(best, prev[d - 1] + P1)
+                        if d < D - 1:
+                            best = min(best, prev[d + 1] + P1)
+                        best = min(best, m + P2)
+                        cur[d] = c[d, y, x] + best - m
+                acc[:, y, x] = cur
+                prev = cur
+        total += acc
+    total *= 0.25
+    return total
+
+
+def test_hslo_second_opinion(orc):
+    """The path costs of the four directions and their mean (float64 restatement vs the float32 oracle), and the WTA map
+    wherever the float64 minimum is clear of float32 rounding."""
+    H, W, D, zd = 9, 13, 6, 2
+    L, R = rand_pair(H, W, 31)
+    cl, _ = orc.ci_adcensus(L, R, 10.0, 30.0, D, zd)
+    disp, vol = orc.dc_hslo(cl, L, R, 15.0, 1.0, 3.0, zd, return_cost=True)
+    want = _hslo_py(cl, L, R, 15.0, 1.0, 3.0, zd)
+    assert np.max(np.abs(vol.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-3)) < 1e-5
+    srt = np.sort(want, axis=0)
+    clear = (srt[1] - srt[0]) > 1e-4  # pixels whose best hypothesis is not a near-tie
+    assert clear.mean() > 0.5
+    assert np.array_equal(disp[clear], (np.argmin(want, axis=0) - zd).astype(np.float32)[clear])
+    # penalty classes: same costs, an image with a strong vertical edge (steps > T: penalties / 10 there) vs a flat image
+    flat = np.full((H, W, 3), 90, np.uint8)
+    edge = flat.copy()
+    edge[:, W // 2:] = 200
+    _, v_flat = orc.dc_hslo(cl, flat, flat, 15.0, 1.0, 3.0, zd, return_cost=True)
+    _, v_edge = orc.dc_hslo(cl, edge, edge, 15.0, 1.0, 3.0, zd, return_cost=True)
+    assert np.allclose(v_flat, _hslo_py(cl, flat, flat, 15.0, 1.0, 3.0, zd), rtol=1e-5, atol=1e-5)
+    assert np.allclose(v_edge, _hslo_py(cl, edge, edge, 15.0, 1.0, 3.0, zd), rtol=1e-5, atol=1e-5)
+    assert float(v_edge.mean()) < float(v_flat.mean())  # smaller penalties across the edge: cheaper paths on average
+
+
+# ------------------------------------------------------------------------------------------------ forward warp (a23)
+def _fwarp_py(img_l, disp_l, shift):
+    """Scatter out[clamp(x + int(disp * shift))] = in[x]; among sources that land on one target the LARGEST x wins (the
+    deterministic rule DESIGN.md fixes for the reference's racy scatter); untouched targets stay 0."""
+    H, W, _ = img_l.shape
+    out = np.zeros_like(img_l)
+    for y in range(H):
+        owner = {}
+        for x in range(W):
+            sd = int(np.float32(disp_l[y, x]) * np.float32(shift))  # int() truncates toward zero like the C cast
+            owner[min(max(x + sd, 0), W - 1)] = x
+        for t, x in owner.items():
+            out[y, t] = img_l[y, x]
+    return out
+
+
+def test_forward_warp_second_opinion(orc):
+    rng = np.random.RandomState(8)
+    H, W = 11, 23
+    L, R = rand_pair(H, W, 8)
+    dl = rng.randint(-9, 10, size=(H, W)).astype(np.float32) + rng.choice([0.0, 0.25, 0.5], size=(H, W)).astype(np.float32)
+    for shift in (0.5, 1.0, -0.75, 0.0):
+        assert np.array_equal(orc.dibr_dfm(L, R, dl, dl, shift), _fwarp_py(L, dl, shift))
+
+
+# ------------------------------------------------------------------------------------------------ 3x3 "median" (d_filter.cu:7-45)
+def _median_py(img):
+    """Nine samples in[(x+dx) + (y+dy) W] of the FLAT buffer (a column step off the row wraps into the neighbouring row; a
+    flat index outside the buffer is clamped), selection sort on the values truncated to int where a swap stores the
+    truncated ints back; the result is slot 4."""
+    H, W = img.shape
+    flat = img.ravel()
+    out = np.empty(H * W, np.float32)
+    for y in range(H):
+        for x in range(W):
+            v = []
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    q = min(max((x + dx) + (y + dy) * W, 0), H * W - 1)
+                    v.append(float(flat[q]))
+            for i in range(9):
+                cur = int(v[i])
+                for j in range(i, 9):
+                    comp = int(v[j])
+                    if comp < cur:
+                        v[j], v[i] = float(cur), float(comp)
+                        cur = comp
+            out[y * W + x] = v[4]
+    return out.reshape(H, W)
+
+
+@pytest.mark.parametrize("H,W", [(7, 9), (3, 3), (1, 5)])
+def test_median_second_opinion(orc, H, W):
+    rng = np.random.RandomState(H * 31 + W)
+    img = (rng.randint(-6, 7, size=(H, W)) + rng.choice([0.0, 0.5, 0.75], size=(H, W))).astype(np.float32)
+    assert np.array_equal(orc.filter_median(img), _median_py(img))
+
+
+# ------------------------------------------------------------------------------------------------ tx_scale (d_tx_scale.cu:8-52)
+def _bilinear_py(img, out_rows, out_cols, as_u8):
+    """Sample position (gx / out_cols * in_cols, gy / out_rows * in_rows) clamped to the image, floor corner, +1 neighbour
+    clamped at the border, weights from the fractional parts; u8 images truncate the blend."""
+    H, W = img.shape[:2]
+    src = img.astype(np.float64)
+    out = np.zeros((out_rows, out_cols) + img.shape[2:], np.float64)
+    for gy in range(out_rows):
+        for gx in range(out_cols):
+            xs = min(max(float(np.float32(np.float32(gx) / np.float32(out_cols)) * np.float32(W)), 0.0), W - 1.0)
+            ys = min(max(float(np.float32(np.float32(gy) / np.float32(out_rows)) * np.float32(H)), 0.0), H - 1.0)
+            x0, y0 = int(np.floor(xs)), int(np.floor(ys))
+            x1, y1 = min(x0 + 1, W - 1), min(y0 + 1, H - 1)
+            wx, wy = xs - x0, ys - y0
+            top = src[y0, x0] * (1 - wx) + src[y0, x1] * wx
+            bot = src[y1, x0] * (1 - wx) + src[y1, x1] * wx
+            out[gy, gx] = top * (1 - wy) + bot * wy
+    return out
+
+
+def test_tx_scale_second_opinion(orc):
+    L, _ = rand_pair(12, 20, 3)
+    for (h, w) in [(6, 10), (24, 40), (7, 13), (12, 20)]:
+        got = orc.tx_scale_bilinear(L, h, w).astype(np.float64)
+        want = _bilinear_py(L, h, w, True)
+        # u8 truncation of a float32 blend: equal to the float64 blend's floor except where the blend sits within rounding
+        # distance of an integer
+        diff = got - np.floor(want + 1e-4)
+        near_int = np.abs(want - np.round(want)) < 1e-3
+        assert np.all((diff == 0) | near_int) and np.abs(got - want).max() < 1.0 + 1e-3
+    rng = np.random.RandomState(5)
+    d = (rng.randint(-8, 9, size=(9, 14)) + rng.random_sample((9, 14))).astype(np.float32)
+    for (h, w, scale) in [(18, 28, 2.0), (9, 14, 1.0), (13, 9, 0.5)]:
+        got = orc.tx_disp_scale(d, h, w, scale).astype(np.float64)
+        want = _bilinear_py(d, h, w, False) * scale
+        assert np.max(np.abs(got - want)) < 1e-4
