@@ -64,6 +64,7 @@ def cpu_baseline_and_parity(sbs, p, H, W, D, zd, stages, run_gpu):
     that sample and every output is compared with the oracle's, element by element."""
     from oracle import pyoracle as orc
     orc.build()
+    orc.limit_threads_to_usable_cpus()
     hslo = bool(stages & 0x100)
 
     def run(rows):
@@ -73,7 +74,7 @@ def cpu_baseline_and_parity(sbs, p, H, W, D, zd, stages, run_gpu):
                                 p.lsd, p.thresh_s, p.thresh_h, hslo=hslo)
         return time.perf_counter() - t0, part, want
 
-    rows = max(H // 4, 64) if orc.num_threads() < 32 else H
+    rows = max(H // 4, 64) if orc.num_threads() < 8 else H
     rows = min(rows, H)
     dt, part, want = run(rows)
     fps = (1.0 / dt) * (rows / float(H))

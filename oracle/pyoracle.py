@@ -55,6 +55,26 @@ def num_threads():
     return int(lib().orc_num_threads())
 
 
+def usable_cpus():
+    """CPUs this process may really use: the smaller of the scheduler affinity and the cgroup CPU quota (a container with
+    a 16-CPU share on a 256-thread host runs 256 OpenMP threads far slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def limit_threads_to_usable_cpus():
+    """Timed runs (bench.py's cpu_baseline, tools/c1_cpu_timing.py): one OpenMP thread per usable CPU.  Returns the count."""
+    n = min(num_threads(), usable_cpus())
+    lib().orc_set_num_threads(n)
+    return num_threads()
+
+
 def grey(img):
     H, W, E = img.shape
     img, pi = _u8(img)

@@ -305,13 +305,57 @@ __device__ __forceinline__ ArmWords load_arm_words(const u8 *__restrict__ armU, 
     return a;
 }
 
+// One wave tile = 16 rows x 4 columns x 16 hypotheses = ONE v_mfma_f32_16x16x1_4B_f32 per window row: block b = column,
+// A[m] = mask of pixel (row m, column b) (lane 16 b + m), B[n] = cost of hypothesis n at (window row, column b) (lane 16 b + n),
+// D: register 4b + i of lane 16q + n = out[row 4q + i][column b][hypothesis n].  `ring`: rows of float [4 columns][16 hyp.].
+// Window of the lane's pixel: [s0, s0 + nn).  Returns the 16 accumulators.
+__device__ __forceinline__ f16v v12_window_sums(const float *ring, int R, int slot_rd, int y0, int s0, int nn, int l, int dbg)
+{
+    const int lo = wave_min_i(nn ? s0 : 0x7fffffff);
+    const int hi = wave_max_i(nn ? s0 + nn : -0x7fffffff);
+    f16v acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if (hi > lo && !(dbg & 1)) {
+        const int K0 = lo & ~3; // multiple of 4 (two's complement floor), as R is: a 4-row read never wraps
+        const int n_it = (dbg & 2) ? 12 : (hi - K0 + 3) >> 2; // dbg: timing experiments only
+        int tt = K0 - s0;
+        int sl = slot_rd + (K0 - y0); // K0 - y0 in [-usd - 3, 15]
+        if (sl < 0) sl += R;
+        if (sl >= R) sl -= R;
+        const float *p = ring + sl * 64 + l;
+        const float *const pend = ring + R * 64 + l; // this lane's address one ring length on
+        for (int it = 0; it < n_it; ++it) {
+            const float c0 = p[0], c1 = p[64], c2 = p[128], c3 = p[192]; // four window rows
+            p += 256;
+            if (p >= pend) p -= R * 64;
+            const float m0 = ((unsigned)tt < (unsigned)nn) ? 1.0f : 0.0f;
+            const float m1 = ((unsigned)(tt + 1) < (unsigned)nn) ? 1.0f : 0.0f;
+            const float m2 = ((unsigned)(tt + 2) < (unsigned)nn) ? 1.0f : 0.0f;
+            const float m3 = ((unsigned)(tt + 3) < (unsigned)nn) ? 1.0f : 0.0f;
+            tt += 4;
+            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m0, c0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m1, c1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m2, c2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m3, c3, acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
+// The two passes run in DIFFERENT code paths (both execute the same two barriers per step): the first-pass waves do every
+// global LOAD of the block (input rows two steps ahead, the next tile's arm bytes) and no store, the second-pass waves do
+// every global STORE and no load (they take their windows from a small LDS ring the first-pass waves fill).  s_waitcnt counts
+// loads and stores together, in issue order: with both in one wave, waiting for an old load dragged in that step's
+// freshly issued rows (the compiler cannot count conditional stores) and every step paid the HBM latency.
 template <int NTP>
 __global__ __launch_bounds__(128 * NTP) void stm_k_pq_v12(PQViews v, int H, int W, int G, int NC, int usd, int R1, int R2, int LAG, int dbg)
 {
-    constexpr int PV_TS = 16 * NTP, NTH = 128 * NTP, LB = 8 * NTP; // rows per step, threads, rows per load batch
+    constexpr int PV_TS = 16 * NTP, NTH = 128 * NTP, LB = 4 * NTP; // rows per step, threads, rows per load batch (first-pass waves)
     extern __shared__ float ldsf[];
     // rings of rows; a row = float [4 columns][16 hypotheses] (256 B): lane 16 b + n of a wave reads its B operand linearly
     float *ring1 = ldsf, *ring2 = ldsf + R1 * 64;
+    int2 *wring = (int2 *)(ldsf + (R1 + R2) * 64); // [LAG + 1][NTP][64]: windows (s0, nn) of the tiles of the last LAG + 1 steps
     const int view = blockIdx.z, c = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const f4 *__restrict__ in = (const f4 *)(view ? v.b[1] : v.b[0]) + ((size_t)c * H * G + g) * 16;
     f4 *__restrict__ out = (f4 *)(view ? v.a[1] : v.a[0]) + ((size_t)c * H * G + g) * 16;
@@ -322,127 +366,111 @@ __global__ __launch_bounds__(128 * NTP) void stm_k_pq_v12(PQViews v, int H, int 
     const int l = tid & 63, wv = (tid >> 6) >= NTP, ti = (tid >> 6) - (wv ? NTP : 0); // pass, tile of the step
     const int lb = l >> 4, dd = l & 15; // A: column / row;  B: column / hypothesis;  D: row quad / hypothesis
     const int nT = (H + 15) >> 4, nS = (nT + NTP - 1) / NTP; // tiles of 16 rows, steps
-    const float *ring = wv ? ring2 : ring1;
-    const int R = wv ? R2 : R1;
-    // rows of the input volume: the strip's row r is one 256-B piece; thread t loads piece (t / 16) of a LB-row batch
-    const int lrow = tid >> 4, ldd = tid & 15;
     __syncthreads();
-    // rows needed by step 0: [0, TS + usd - 1); four loads in flight per thread
-    int loaded = min(PV_TS + usd - 1, H);
-    for (int r0 = 0; r0 < loaded; r0 += 4 * LB) {
-        f4 tmp[4];
+    if (!wv) {
+        // ---------------------------------------------------------------- first pass: ring 1 -> ring 2, all loads
+        const int lrow = tid >> 4; // 0 .. 4 NTP - 1: the strip's row r is one 256-B piece, 16 lanes each
+        // rows needed by step 0: [0, TS + usd - 1); four loads in flight per thread
+        int loaded = min(PV_TS + usd - 1, H);
+        for (int r0 = 0; r0 < loaded; r0 += 4 * LB) {
+            f4 tmp[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) tmp[k] = nt_load4(in + (size_t)min(r0 + LB * k + lrow, H - 1) * rstride + ldd);
+            for (int k = 0; k < 4; ++k) tmp[k] = nt_load4(in + (size_t)min(r0 + LB * k + lrow, H - 1) * rstride + dd);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = r0 + LB * k + lrow;
-            if (r < loaded) {
-                float *q = ring1 + (r % R1) * 64 + ldd;
-                q[0] = tmp[k].x; q[16] = tmp[k].y; q[32] = tmp[k].z; q[48] = tmp[k].w;
+            for (int k = 0; k < 4; ++k) {
+                const int r = r0 + LB * k + lrow;
+                if (r < loaded) {
+                    float *q = ring1 + (r % R1) * 64 + dd;
+                    q[0] = tmp[k].x; q[16] = tmp[k].y; q[32] = tmp[k].z; q[48] = tmp[k].w;
+                }
             }
         }
-    }
-    int slot_ld = loaded % R1; // ring-1 slot of row `loaded`
-    // input rows travel two steps ahead of their use (HBM latency under load exceeds one step): `pre` holds the rows the NEXT
-    // step adds (issued one step ago, written to the ring at the end of this step), `far` the rows of the step after that
-    f4 pre[2];
+        int slot_ld = loaded % R1; // ring-1 slot of row `loaded`
+        // input rows travel two steps ahead of their use (HBM latency under load exceeds one step): `pre` holds the rows the
+        // NEXT step adds (issued one step ago, written to the ring at the end of this step), `far` those of the step after
+        f4 pre[4];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) pre[k] = nt_load4(in + (size_t)min(loaded + LB * k + lrow, H - 1) * rstride + ldd);
-    // this wave's tile of step t is u = NTP t + ti (first pass) or NTP (t - LAG) + ti (second pass); its arm bytes are fetched
-    // one step ahead: every lane fetches the dword (columns 4g..4g+3) of row (lane % 16) and keeps the byte of its column
-    int u = (wv ? -LAG * NTP : 0) + ti;
-    int slot_rd = (16 * ti) % R, slot_wr = (16 * ti) % R2; // slots of the tile's first row in the ring this wave reads / in ring 2
-    ArmWords nxt = load_arm_words(armU, armD, max(u, 0) * 16 + dd, g, H, W);
-    // window of this lane's pixel (row y0 + dd, column 4g + lb) of the tile about to be computed: [s0, s0 + nn), decoded from
-    // the arm bytes at the END of the step before -- there the only younger loads in flight are that step's two row loads, so
-    // the wait for the bytes (s_waitcnt counts in issue order) does not drag the rows in
-    int s0, nn;
+        for (int k = 0; k < 4; ++k) pre[k] = nt_load4(in + (size_t)min(loaded + LB * k + lrow, H - 1) * rstride + dd);
+        int u = ti; // this wave's tile of step t: u = NTP t + ti
+        int slot_rd = (16 * ti) % R1, slot_wr = (16 * ti) % R2;
+        // arm bytes: every lane fetches the dword (columns 4g..4g+3) of row (lane % 16) and keeps the byte of its column
+        ArmWords nxt = load_arm_words(armU, armD, u * 16 + dd, g, H, W);
+        int s0, nn;
 #define STM_V_DECODE(U)                                                                                  \
     {                                                                                                    \
         const int yy_ = (U) * 16 + dd;                                                                   \
         const int aU_ = (int)((nxt.u >> (8 * lb)) & 0xffu), aD_ = (int)((nxt.d >> (8 * lb)) & 0xffu);    \
-        s0 = yy_ - aU_;                                                                                  \
-        nn = ((U) >= 0 && yy_ < H && 4 * g + lb < W) ? aU_ + aD_ : 0;                                    \
+        s0 = yy_ - aU_;                               /* window [y - armU, y + armD) */                  \
+        nn = (yy_ < H && 4 * g + lb < W) ? aU_ + aD_ : 0;                                                \
     }
-    STM_V_DECODE(u)
-    for (int t = 0; t < nS + LAG; ++t, u += NTP) {
-        __syncthreads(); // ring 1 holds the rows of this step; ring 2 the first-pass rows of the steps before
-        const int y0 = u * 16;
-        // the next tile's arm bytes, then rows [loaded + TS, loaded + 2 TS); all unconditional (clamped rows)
-        nxt = load_arm_words(armU, armD, max(u + NTP, 0) * 16 + dd, g, H, W);
-        f4 far[2];
+        STM_V_DECODE(u)
+        for (int t = 0; t < nS + LAG; ++t, u += NTP) {
+            __syncthreads(); // ring 1 holds the rows of this step
+            const int y0 = u * 16;
+            nxt = load_arm_words(armU, armD, (u + NTP) * 16 + dd, g, H, W);
+            f4 far[4];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) far[k] = nt_load4(in + (size_t)min(loaded + PV_TS + LB * k + lrow, H - 1) * rstride + ldd);
-        if (u >= 0 && u < nT) {
-            const int lo = wave_min_i(nn ? s0 : 0x7fffffff);
-            const int hi = wave_max_i(nn ? s0 + nn : -0x7fffffff);
-            f16v acc;
+            for (int k = 0; k < 4; ++k) far[k] = (dbg & 4) ? pre[k] : nt_load4(in + (size_t)min(loaded + PV_TS + LB * k + lrow, H - 1) * rstride + dd);
+            if (u < nT) {
+                wring[((t % (LAG + 1)) * NTP + ti) * 64 + l] = make_int2(s0, nn);
+                const f16v acc = v12_window_sums(ring1, R1, slot_rd, y0, s0, nn, l, dbg);
+                // register 4b + i of lane 16q + n = out[row y0 + 4q + i][column 4g + b][hypothesis 16c + n]
+                int so = slot_wr + 4 * lb; // ring 2's slot of the lane's four output rows
+                if (so >= R2) so -= R2;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            if (hi > lo && !(dbg & 1)) {
-                const int K0 = lo & ~3; // multiple of 4 (two's complement floor), as R is: a 4-row read never wraps
-                const int n_it = (hi - K0 + 3) >> 2;
-                int tt = K0 - s0;
-                int sl = slot_rd + (K0 - y0); // K0 - y0 in [-usd - 3, 15]
-                if (sl < 0) sl += R;
-                if (sl >= R) sl -= R;
-                const float *p = ring + sl * 64 + l;
-                const float *const pend = ring + R * 64 + l; // this lane's address one ring length on
-                for (int it = 0; it < n_it; ++it) {
-                    const float c0 = p[0], c1 = p[64], c2 = p[128], c3 = p[192]; // four window rows
-                    p += 256;
-                    if (p >= pend) p -= R * 64;
-                    const float m0 = ((unsigned)tt < (unsigned)nn) ? 1.0f : 0.0f;
-                    const float m1 = ((unsigned)(tt + 1) < (unsigned)nn) ? 1.0f : 0.0f;
-                    const float m2 = ((unsigned)(tt + 2) < (unsigned)nn) ? 1.0f : 0.0f;
-                    const float m3 = ((unsigned)(tt + 3) < (unsigned)nn) ? 1.0f : 0.0f;
-                    tt += 4;
-                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m0, c0, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m1, c1, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m2, c2, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m3, c3, acc, 0, 0, 0);
-                }
-            }
-            // register 4b + i of lane 16q + n = out[row y0 + 4q + i][column 4g + b][hypothesis 16c + n]
-            int so = slot_wr + 4 * lb; // ring 2's slot of the lane's four output rows (first pass only)
-            if (so >= R2) so -= R2;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = y0 + 4 * lb + i;
-                if (r < H) {
-                    if (wv) {
-                        const f4 o = {acc[i], acc[4 + i], acc[8 + i], acc[12 + i]};
-                        nt_store4(out + (size_t)r * rstride + dd, o);
-                    } else {
+                for (int i = 0; i < 4; ++i)
+                    if (y0 + 4 * lb + i < H) {
                         float *q = ring2 + (so + i) * 64 + dd;
                         q[0] = acc[i]; q[16] = acc[4 + i]; q[32] = acc[8 + i]; q[48] = acc[12 + i];
                     }
+                slot_rd += PV_TS;
+                if (slot_rd >= R1) slot_rd -= R1;
+                slot_wr += PV_TS;
+                if (slot_wr >= R2) slot_wr -= R2;
+            }
+            __syncthreads(); // everyone is done reading ring 1: the oldest TS rows can be replaced
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = loaded + LB * k + lrow;
+                int sw = slot_ld + LB * k + lrow;
+                if (sw >= R1) sw -= R1;
+                if (r < H) {
+                    float *q = ring1 + sw * 64 + dd;
+                    q[0] = pre[k].x; q[16] = pre[k].y; q[32] = pre[k].z; q[48] = pre[k].w;
                 }
             }
-            slot_rd += PV_TS;
-            if (slot_rd >= R) slot_rd -= R;
-            slot_wr += PV_TS;
-            if (slot_wr >= R2) slot_wr -= R2;
-        }
-        __syncthreads(); // everyone is done reading ring 1: the oldest TS rows can be replaced
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int r = loaded + LB * k + lrow;
-            int sw = slot_ld + LB * k + lrow;
-            if (sw >= R1) sw -= R1;
-            if (r < H) {
-                float *q = ring1 + sw * 64 + ldd;
-                q[0] = pre[k].x; q[16] = pre[k].y; q[32] = pre[k].z; q[48] = pre[k].w;
-            }
+            for (int k = 0; k < 4; ++k) pre[k] = far[k];
+            STM_V_DECODE(u + NTP)
+            loaded += PV_TS; // keeps advancing past H so that later steps load nothing
+            slot_ld += PV_TS;
+            if (slot_ld >= R1) slot_ld -= R1;
         }
-        pre[0] = far[0];
-        pre[1] = far[1];
-        STM_V_DECODE(u + NTP)
-        loaded += PV_TS; // keeps advancing past H so that later steps load nothing
-        slot_ld += PV_TS;
-        if (slot_ld >= R1) slot_ld -= R1;
-    }
 #undef STM_V_DECODE
+    } else {
+        // ---------------------------------------------------------------- second pass: ring 2 -> HBM, all stores, LAG steps behind
+        int u = -LAG * NTP + ti;
+        int slot_rd = (16 * ti) % R2;
+        for (int t = 0; t < nS + LAG; ++t, u += NTP) {
+            __syncthreads(); // ring 2 holds the first-pass rows of the steps before
+            if (u >= 0 && u < nT) {
+                const int y0 = u * 16;
+                const int2 w = wring[(((t - LAG) % (LAG + 1)) * NTP + ti) * 64 + l]; // written by the first pass at step t - LAG
+                const f16v acc = v12_window_sums(ring2, R2, slot_rd, y0, w.x, w.y, l, dbg);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = y0 + 4 * lb + i;
+                    if (r < H && !(dbg & 4)) {
+                        const f4 o = {acc[i], acc[4 + i], acc[8 + i], acc[12 + i]};
+                        nt_store4(out + (size_t)r * rstride + dd, o);
+                    }
+                }
+                slot_rd += PV_TS;
+                if (slot_rd >= R2) slot_rd -= R2;
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // ------------------------------------------------------------------ launchers
@@ -455,7 +483,7 @@ static size_t v12_smem(int usd, int ntp)
     const int R1 = (TS + 2 * usd + 3) & ~3;
     const int LAG = (usd > 1 ? (usd - 1 + TS - 1) / TS : 0) + 1;
     const int R2 = (TS * (LAG + 1) + usd + 3) & ~3;
-    return (size_t)(R1 + R2) * 256;
+    return (size_t)(R1 + R2) * 256 + (size_t)(LAG + 1) * ntp * 64 * 8; // + the ring of windows the first pass hands to the second
 }
 // arms longer than this do not fit the CU's 160 KB: the caller falls back to the vector-ALU kernels (stm_kernels_agg.hip)
 bool aggm_supports(int usd) { return usd >= 1 && v12_smem(usd > 255 ? 255 : usd, 3) <= 160 * 1024; }
@@ -504,7 +532,7 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
         const int R1 = (TS + 2 * usd + 3) & ~3;
         const int LAG = (usd > 1 ? (usd - 1 + TS - 1) / TS : 0) + 1; // the second pass may use first-pass rows of EARLIER steps only
         const int R2 = (TS * (LAG + 1) + usd + 3) & ~3;
-        const size_t smem = (size_t)(R1 + R2) * 256;
+        const size_t smem = v12_smem(usd, ntp);
         const int dbg = (agg_variant() / 100000) % 10;
 #define STM_LAUNCH_V12(N)                                                                                                       \
     {                                                                                                                           \

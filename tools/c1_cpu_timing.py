@@ -15,6 +15,7 @@ L, R = stm_amd.bmp_io.read_bmp(os.path.join(GOLD, "bud_2.bmp")), stm_amd.bmp_io.
 D, zd, ad, ce, ucd, lcd, usd, lsd, ts, th, N, angle = [float(x) for x in g["params"]]
 D, zd, usd, lsd, ts, N = int(D), int(zd), int(usd), int(lsd), int(ts), int(N)
 H, W, _ = L.shape
+orc.limit_threads_to_usable_cpus()
 stage = {}
 def timed(name, f, *a, **k):
     t0 = time.perf_counter(); r = f(*a, **k); stage[name] = stage.get(name, 0.0) + (time.perf_counter() - t0) * 1e3; return r
