@@ -22,6 +22,12 @@ def per_kernel(path, counter):
 
 def short(name):
     n = name.split("(")[0].replace("void ", "").replace("stm::", "")
+    if "stm_k_pq_h" in n:
+        args = n[n.index("<") + 1:n.index(">")].split(", ")
+        return "pq_hw" if len(args) >= 2 and args[1] == "true" else "pq_h"   # <NW, WTA, ...>
+    for k in ("pq_v12", "pq_cost"):
+        if k in n:
+            return k
     if "agg_h" in n:
         args = n[n.index("<") + 1:n.index(">")].split(", ") if "<" in n else []
         if len(args) >= 2 and args[1] == "true":
@@ -46,7 +52,8 @@ def main():
         w = write.get(k, 0.0) * 1024.0
         # the x2 applies to kernels that stream a quad volume with 16 B/lane loads; the on-the-fly cost pass reads only
         # dword planes (pixels, census, arms)
-        corr = 2.0 if (("agg_" in k and short(k) != "agg_h_cost") or "cost_init" in k) else 1.0
+        # matrix-pipe kernels: pq_h / pq_hw / pq_v12 stream the volume as 16-byte elements; pq_cost reads dword planes
+        corr = 2.0 if (("agg_" in k and short(k) != "agg_h_cost") or "cost_init" in k or short(k) in ("pq_h", "pq_hw", "pq_v12")) else 1.0
         out[short(k)] = {"kernel": k.split("(")[0], "fetch_raw_bytes": f_raw, "fetch_correction": corr,
                          "write_bytes": w, "traffic_bytes": f_raw * corr + w}
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
