@@ -128,7 +128,7 @@ __global__ __launch_bounds__(PC_TX) void stm_k_pq_cost(PQViews v, const float *_
 // LDS: float4 tile[4 chunks][NG groups][16] | u32 sn[16 NW] (window start relative to the tile | length << 16).
 // Lane l: pt = l / 16 (pixel tile), dq = (l / 4) % 4 (quad of the chunk = step slot of the mask), i = l % 4.
 template <int NW, bool WTA, bool NTFILL>
-__global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, int H, int W, int G, int NC, int HG, int nseg)
+__global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, int H, int W, int G, int NC, int HG, int nseg, int dbg)
 {
     constexpr int NT = 64 * NW, TX = 16 * NW;
     extern __shared__ f4 lds4[];
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, 
                 const int cl = k & 3, r = r0 + (k >> 2) * NT + tid;
                 const f4 *__restrict__ rowp = in + ((size_t)min(c0 + cl, NC - 1) * H + y) * G * 16; // uniform: scalar base
                 const int g = min(max(gbase + (r >> 4), 0), G - 1);
-                tmp[k] = NTFILL ? nt_load4(rowp + (g * 16 + (r & 15))) : rowp[g * 16 + (r & 15)];
+                tmp[k] = (dbg & 4) ? zero4 : (NTFILL ? nt_load4(rowp + (g * 16 + (r & 15))) : rowp[g * 16 + (r & 15)]);
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -518,10 +518,10 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
         ProfScope p("pq_h");
         if (ntfill) {
             allow_lds_m((const void *)stm_k_pq_h<NW, false, true>, smem_h);
-            STM_LAUNCH((stm_k_pq_h<NW, false, true>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
+            STM_LAUNCH((stm_k_pq_h<NW, false, true>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, (agg_variant() / 100000) % 10);
         } else {
             allow_lds_m((const void *)stm_k_pq_h<NW, false, false>, smem_h);
-            STM_LAUNCH((stm_k_pq_h<NW, false, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
+            STM_LAUNCH((stm_k_pq_h<NW, false, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, (agg_variant() / 100000) % 10);
         }
         STM_CHECK_LAUNCH();
     }
@@ -550,10 +550,10 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
         ProfScope p("pq_hw");
         if (ntfill) {
             allow_lds_m((const void *)stm_k_pq_h<NW, true, true>, smem_h);
-            STM_LAUNCH((stm_k_pq_h<NW, true, true>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
+            STM_LAUNCH((stm_k_pq_h<NW, true, true>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, (agg_variant() / 100000) % 10);
         } else {
             allow_lds_m((const void *)stm_k_pq_h<NW, true, false>, smem_h);
-            STM_LAUNCH((stm_k_pq_h<NW, true, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg);
+            STM_LAUNCH((stm_k_pq_h<NW, true, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, (agg_variant() / 100000) % 10);
         }
         STM_CHECK_LAUNCH();
     }
