@@ -560,7 +560,7 @@ def test_frame_stream_graph_replay_survives_other_calls(gpu_ready, orc):
         assert np.array_equal(got[k][1], dl) and np.array_equal(got[k][2], dr) and np.array_equal(got[k][3], out), k
 
 
-def test_video_cli_roundtrip(gpu_ready, tmp_path):
+def test_video_cli_roundtrip(gpu_ready, orc, tmp_path):
     import subprocess
     import sys
     from conftest import ROOT
@@ -574,6 +574,10 @@ def test_video_cli_roundtrip(gpu_ready, tmp_path):
     subprocess.check_call(args)
     assert sorted(os.listdir(out)) == sorted(["%s_%05d.bmp" % (n, k) for n in ("interlaced", "disp_l", "disp_r") for k in range(3)])
     assert bmp_io.read_bmp(str(out / "interlaced_00001.bmp")).shape == (H, W, 3)
+    # like the reference binary, the tool truncates the slant (adcensus_stm takes `int angle`, d_io.h:36): 18.43 -> 18
+    f1 = synth.sbs_frame(H, W, D, zd, seed=synth.SEED + 1)[0]
+    want = orc.adcensus_stm(f1, H, W, 8, 18.0, D, zd, 10.0, 30.0, 6.0, 20.0, 9, 4, 20, 0.4)
+    assert np.array_equal(bmp_io.read_bmp(str(out / "interlaced_00001.bmp")), want["interlaced"])
 
 
 # ----------------------------------------------------------------------------- HSLO (parity unpinned: oracle-defined)

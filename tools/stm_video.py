@@ -4,7 +4,9 @@ side-by-side BMP frames instead of a video file, BMP outputs instead of a window
 
 usage: stm_video.py <frames dir> <num views> <angle> <out width> <out height> <num disp> <zero disp> <ad coeff>
                     <census coeff> <ucd> <lcd> <usd> <lsd> <thresh_s> <thresh_h> [out dir]
-(the 15 arguments of video_io.cpp:49-109; frames are *.bmp, sorted by name)"""
+(the 15 arguments of video_io.cpp:49-109; frames are *.bmp, sorted by name)
+The angle is truncated to an integer as the reference does (adcensus_stm declares `int angle`, d_io.h:36, and video_io.cpp:158
+passes it a float); set STM_EXACT_ANGLE=1 to keep the fractional slant."""
 import os
 import sys
 import time
@@ -20,7 +22,8 @@ def main(argv):
     import stm_amd  # noqa: F401
     from stm_amd import device_api as dev, video
     a = argv[1:]
-    p = dev.FrameParams(num_views=int(a[1]), angle=float(a[2]), num_disp=int(a[5]), zero_disp=int(a[6]), ad_coeff=float(a[7]),
+    angle = float(a[2]) if os.environ.get("STM_EXACT_ANGLE") == "1" else float(int(float(a[2])))  # SURVEY A-Q24
+    p = dev.FrameParams(num_views=int(a[1]), angle=angle, num_disp=int(a[5]), zero_disp=int(a[6]), ad_coeff=float(a[7]),
                         census_coeff=float(a[8]), ucd=float(a[9]), lcd=float(a[10]), usd=int(a[11]), lsd=int(a[12]),
                         thresh_s=int(a[13]), thresh_h=float(a[14]))
     out_w, out_h = int(a[3]), int(a[4])
