@@ -180,11 +180,14 @@ def main():
         V = float(D) * H * W * 4
         HW = float(H) * W
         # algorithmic bytes per launch (compulsory inputs + outputs, each buffer once).  The matrix-pipe kernels
-        # serve BOTH views per launch: pq_cost writes 2 V from 4 dword planes per view; pq_h reads and writes a volume per
-        # view (+ 2 arm planes); pq_v12 = both vertical passes fused (K2 of SURVEY 8d): V in, V out, 2 arm planes per view;
+        # serve BOTH views per launch: pq_h = first horizontal pass; pq_v12 = both vertical passes fused (K2 of SURVEY 8d): V in, V out, 2 arm planes per view;
         # pq_hw = last pass + WTA: V in, 2 arm planes, disparity out.  Vector-ALU kernels (--agg-variant 10000): as round 1.
         hslo = bool(args.stages & 0x100)
-        alg = {"pq_cost": 2 * V + 16 * HW, "pq_h": 2 * (2 * V + 2 * HW), "pq_v12": 2 * (2 * V + 2 * HW), "pq_hw": 2 * (V + 6 * HW),
+        # By default the first pass computes the initial costs itself (no pq_cost launch): per view it reads four dword planes
+        # (BGRX + census of both images) and two arm planes and writes V -- SURVEY 8d's K1; the frame then moves 8 V.
+        fused_cost = "pq_cost" not in kern
+        alg = {"pq_cost": 2 * V + 16 * HW, "pq_h": 2 * (V + 18 * HW) if fused_cost else 2 * (2 * V + 2 * HW),
+               "pq_v12": 2 * (2 * V + 2 * HW), "pq_hw": 2 * (V + 6 * HW),
                "agg_h": (2 * V + 2 * HW) if hslo else 2 * (V + 2 * HW + 16 * HW), "agg_v": 2 * V + 2 * HW,
                "agg_hw": 2 * (V + 2 * HW + 4 * HW), "cost_init": 2 * V + 4 * 4 * HW}
         traffic_all, traffic_src = {}, None

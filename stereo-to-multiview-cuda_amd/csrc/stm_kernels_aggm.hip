@@ -127,8 +127,13 @@ __global__ __launch_bounds__(PC_TX) void stm_k_pq_cost(PQViews v, const float *_
 // (four pixel tiles of 4) x 64 hypotheses = 4 accumulation chains (one per chunk) that share the mask register.
 // LDS: float4 tile[4 chunks][NG groups][16] | u32 sn[16 NW] (window start relative to the tile | length << 16).
 // Lane l: pt = l / 16 (pixel tile), dq = (l / 4) % 4 (quad of the chunk = step slot of the mask), i = l % 4.
-template <int NW, bool WTA, bool NTFILL>
-__global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, int H, int W, int G, int NC, int HG, int nseg, int dbg)
+// COST: the first pass of the frame.  The tile is not read from a volume but computed in place from the two images (BGRX
+// dwords + census words of this row, staged in LDS with clamped borders) and the two rho tables, as stm_k_pq_cost would have
+// written it: the 2 V of initial costs are never written or read (8 V per frame with the fused vertical kernel, SURVEY 8d's
+// plan), at the price of computing the 2 HG halo groups of every segment twice.
+template <int NW, bool WTA, bool COST>
+__global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, int H, int W, int G, int NC, int HG, int nseg, int dbg,
+                                                      const float *__restrict__ lut_g, int pad)
 {
     constexpr int NT = 64 * NW, TX = 16 * NW;
     extern __shared__ f4 lds4[];
@@ -156,6 +161,25 @@ __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, 
     const size_t row = (size_t)y * W;
     const int gbase = (X0seg >> 2) - HG;
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // COST staging behind the window table: (pixel, census) pairs of the own image (NG * 4) and of the other image (NG * 4 +
+    // 2 pad, clamped to the row), rho tables (768 + 72)
+    uint2 *s_own = (uint2 *)(sn + TX), *s_oth = s_own + NG * 4;
+    float *s_lut_ad = (float *)(s_oth + NG * 4 + 2 * pad), *s_lut_c = s_lut_ad + 768;
+    const int sgn = view ? -1 : 1;
+    if (COST) {
+        const uint32_t *__restrict__ pk_own = view ? v.pk[1] : v.pk[0], *__restrict__ pk_oth = view ? v.pk[0] : v.pk[1];
+        const uint32_t *__restrict__ cen_own = view ? v.cen[1] : v.cen[0], *__restrict__ cen_oth = view ? v.cen[0] : v.cen[1];
+        const int px0 = 4 * gbase; // image column of tile pixel 0
+        for (int i = tid; i < NG * 4; i += NT) {
+            const int gx = min(max(px0 + i, 0), W - 1);
+            s_own[i] = make_uint2(pk_own[row + gx], cen_own[row + gx]);
+        }
+        for (int i = tid; i < NG * 4 + 2 * pad; i += NT) {
+            const int gx = min(max(px0 + i - pad, 0), W - 1); // clamp-to-edge in image coordinates
+            s_oth[i] = make_uint2(pk_oth[row + gx], cen_oth[row + gx]);
+        }
+        for (int i = tid; i < 768 + 65; i += NT) s_lut_ad[i] = lut_g[i];
+    }
 
     if (tid < TX) {
         const int x = X0seg + tid;
@@ -188,6 +212,33 @@ __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, 
         if (cs) __syncthreads(); // the previous chunk set's readers are done with the tile
         // tile fill: every load of a batch is issued before the first LDS write (a load-wait-write loop would expose the full
         // HBM latency once per element); addresses are clamped so that all loads are unconditional, zeros selected afterwards
+        if (COST) {
+            if (cs == 0) __syncthreads(); // staging complete
+            // C(d, x) = rho_ad(|own(x) - other(x')|_1) + rho_c(ham(cen_own(x), cen_other(x'))), x' = clamp(x + sgn (d - zd))
+            // (SURVEY A-Q6); hypotheses d >= D and pixels outside the row are 0
+            // one thread = one (group, hypothesis-in-chunk) pair for all four chunks: the group's own pixels are read once
+            for (int rr = tid; rr < NG * 16; rr += NT) {
+                const int gi = rr >> 4, dd = rr & 15, x0g = 4 * (gbase + gi);
+                const uint2 *own = s_own + gi * 4;
+                const uint2 o0 = own[0], o1 = own[1], o2 = own[2], o3 = own[3];
+                const bool in0 = x0g >= 0 && x0g < W, in1 = x0g + 1 >= 0 && x0g + 1 < W, in2 = x0g + 2 >= 0 && x0g + 2 < W,
+                           in3 = x0g + 3 >= 0 && x0g + 3 < W;
+#pragma unroll
+                for (int cl = 0; cl < 4; ++cl) {
+                    const int d = (c0 + cl) * 16 + dd;
+                    f4 val = zero4;
+                    if (d < D) {
+                        const uint2 *oth = s_oth + gi * 4 + sgn * (d - zd) + pad;
+                        const uint2 q0 = oth[0], q1 = oth[1], q2 = oth[2], q3 = oth[3];
+                        if (in0) val.x = s_lut_ad[__builtin_amdgcn_sad_u8(o0.x, q0.x, 0u)] + s_lut_c[hamdist_q1(o0.y, q0.y)];
+                        if (in1) val.y = s_lut_ad[__builtin_amdgcn_sad_u8(o1.x, q1.x, 0u)] + s_lut_c[hamdist_q1(o1.y, q1.y)];
+                        if (in2) val.z = s_lut_ad[__builtin_amdgcn_sad_u8(o2.x, q2.x, 0u)] + s_lut_c[hamdist_q1(o2.y, q2.y)];
+                        if (in3) val.w = s_lut_ad[__builtin_amdgcn_sad_u8(o3.x, q3.x, 0u)] + s_lut_c[hamdist_q1(o3.y, q3.y)];
+                    }
+                    tile[cl * NG * 16 + rr] = val;
+                }
+            }
+        } else
         for (int r0 = 0; r0 < NG * 16; r0 += 2 * NT) {
             f4 tmp[8];
 #pragma unroll
@@ -195,7 +246,7 @@ __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, 
                 const int cl = k & 3, r = r0 + (k >> 2) * NT + tid;
                 const f4 *__restrict__ rowp = in + ((size_t)min(c0 + cl, NC - 1) * H + y) * G * 16; // uniform: scalar base
                 const int g = min(max(gbase + (r >> 4), 0), G - 1);
-                tmp[k] = (dbg & 4) ? zero4 : (NTFILL ? nt_load4(rowp + (g * 16 + (r & 15))) : rowp[g * 16 + (r & 15)]);
+                tmp[k] = (dbg & 4) ? zero4 : rowp[g * 16 + (r & 15)];
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -500,28 +551,30 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
     }
     const int G = (W + 3) / 4, NC = (D + 15) / 16;
     if (usd > 255) usd = 255;
-    {
+    constexpr int NW = 8;
+    const int HG = (usd + 3) / 4 + 1, NG = 4 * NW + 2 * HG; // halo groups: ceil(usd / 4) on either side of a segment + 1 for the read-ahead
+    const int nseg = cdiv(W, 16 * NW), nblk = ((nseg * H * 2 + 7) / 8) * 8;
+    const size_t smem_h = (size_t)4 * NG * 256 + 16 * NW * 4;
+    const int dbgh = (agg_variant() / 100000) % 10;
+    int pad = zd > D - 1 - zd ? zd : D - 1 - zd;
+    pad = (pad < 0 ? 0 : pad) + 15; // + the padded hypotheses of the last chunk
+    const size_t smem_cost = smem_h + (size_t)(4 * NG * 4 + 4 * pad + 768 + 72) * 4;
+    const bool fuse_cost = (agg_variant() / 1000000) % 10 != 1; // 1: separate stm_k_pq_cost + volume-reading first pass
+    if (!fuse_cost) {
         ProfScope p("pq_cost");
-        int pad = zd > D - 1 - zd ? zd : D - 1 - zd;
-        if (pad < 0) pad = 0;
         const size_t smem = (size_t)(2 * PC_TX + 2 * (PC_TX + 2 * pad) + 768 + 72) * 4;
         allow_lds_m((const void *)stm_k_pq_cost, smem);
         STM_LAUNCH(stm_k_pq_cost, dim3(cdiv(W, PC_TX), H, 2), dim3(PC_TX), smem, stream(), v, lut, D, zd, H, W, G, NC, pad);
         STM_CHECK_LAUNCH();
     }
-    constexpr int NW = 8;
-    const int HG = (usd + 3) / 4 + 1, NG = 4 * NW + 2 * HG; // halo groups: ceil(usd / 4) on either side of a segment + 1 for the read-ahead
-    const int nseg = cdiv(W, 16 * NW), nblk = ((nseg * H * 2 + 7) / 8) * 8;
-    const size_t smem_h = (size_t)4 * NG * 256 + 16 * NW * 4;
-    const bool ntfill = (agg_variant() / 1000000) % 10 == 1;
     {
         ProfScope p("pq_h");
-        if (ntfill) {
-            allow_lds_m((const void *)stm_k_pq_h<NW, false, true>, smem_h);
-            STM_LAUNCH((stm_k_pq_h<NW, false, true>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, (agg_variant() / 100000) % 10);
+        if (fuse_cost) {
+            allow_lds_m((const void *)stm_k_pq_h<NW, false, true>, smem_cost);
+            STM_LAUNCH((stm_k_pq_h<NW, false, true>), dim3(nblk), dim3(64 * NW), smem_cost, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, pad);
         } else {
             allow_lds_m((const void *)stm_k_pq_h<NW, false, false>, smem_h);
-            STM_LAUNCH((stm_k_pq_h<NW, false, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, (agg_variant() / 100000) % 10);
+            STM_LAUNCH((stm_k_pq_h<NW, false, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, 0);
         }
         STM_CHECK_LAUNCH();
     }
@@ -548,13 +601,8 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
     }
     {
         ProfScope p("pq_hw");
-        if (ntfill) {
-            allow_lds_m((const void *)stm_k_pq_h<NW, true, true>, smem_h);
-            STM_LAUNCH((stm_k_pq_h<NW, true, true>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, (agg_variant() / 100000) % 10);
-        } else {
-            allow_lds_m((const void *)stm_k_pq_h<NW, true, false>, smem_h);
-            STM_LAUNCH((stm_k_pq_h<NW, true, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, (agg_variant() / 100000) % 10);
-        }
+        allow_lds_m((const void *)stm_k_pq_h<NW, true, false>, smem_h);
+        STM_LAUNCH((stm_k_pq_h<NW, true, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, 0);
         STM_CHECK_LAUNCH();
     }
 }
