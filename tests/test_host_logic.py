@@ -96,3 +96,35 @@ def test_frame_sharding_two_ranks_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+def test_bench_spawns_its_own_ranks_without_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus 8` outside torch.distributed.run must start the 8 ranks as a CHILD job (one process per GPU,
+    RCCL) before anything in the parent initialises the GPU, and hand the child's exit code back."""
+    import importlib
+    import sys
+    sys.modules.pop("bench", None)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "1"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    cuda_before = "torch" in sys.modules and sys.modules["torch"].cuda.is_initialized()
+    try:
+        bench.main()
+        assert False, "main() must exit with the child's code"
+    except SystemExit as e:
+        assert e.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "5", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    if "torch" in sys.modules:
+        assert sys.modules["torch"].cuda.is_initialized() == cuda_before  # the parent did not initialise the GPU
