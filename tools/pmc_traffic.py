@@ -45,6 +45,7 @@ def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {}
+    fused_cost = not any("pq_cost" in k for k in set(fetch) | set(write))  # the first pass then reads dword planes, not a volume
     for k in sorted(set(fetch) | set(write)):
         if "stm_k_" not in k:
             continue
@@ -53,7 +54,7 @@ def main():
         # the x2 applies to kernels that stream a quad volume with 16 B/lane loads; the on-the-fly cost pass reads only
         # dword planes (pixels, census, arms)
         # matrix-pipe kernels: pq_h / pq_hw / pq_v12 stream the volume as 16-byte elements; pq_cost reads dword planes
-        corr = 2.0 if (("agg_" in k and short(k) != "agg_h_cost") or "cost_init" in k or short(k) in ("pq_h", "pq_hw", "pq_v12")) else 1.0
+        corr = 2.0 if (("agg_" in k and short(k) != "agg_h_cost") or "cost_init" in k or short(k) in ("pq_hw", "pq_v12") or (short(k) == "pq_h" and not fused_cost)) else 1.0
         out[short(k)] = {"kernel": k.split("(")[0], "fetch_raw_bytes": f_raw, "fetch_correction": corr,
                          "write_bytes": w, "traffic_bytes": f_raw * corr + w}
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
