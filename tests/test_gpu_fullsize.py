@@ -133,7 +133,9 @@ def test_ca_cross_rows_between_1024_and_2048(gpu_ready, orc, H, W, D):
 
 @pytest.mark.parametrize("H,W,D,zd,usd,lsd", [(70, 131, 20, 9, 34, 17), (49, 67, 17, 8, 40, 20), (33, 258, 64, 32, 5, 2),
                                               (130, 40, 80, 40, 60, 30), (16, 16, 16, 8, 3, 1), (18, 21, 33, 0, 9, 4),
-                                              (40, 50, 8, 4, 150, 60), (300, 24, 12, 6, 110, 40), (24, 36, 5, 2, 1, 1)])
+                                              (40, 50, 8, 4, 150, 60), (300, 24, 12, 6, 110, 40), (24, 36, 5, 2, 1, 1),
+                                              (1, 1, 1, 0, 3, 1), (2, 3, 2, 1, 5, 2), (3, 5, 1, 0, 34, 17), (1, 70, 4, 2, 9, 4),
+                                              (70, 1, 3, 1, 9, 4), (17, 4, 64, 63, 4, 2), (5, 260, 65, 0, 20, 10)])
 def test_matrix_pipe_aggregation_shapes(gpu_ready, orc, H, W, D, zd, usd, lsd):
     """The frame pipeline's aggregation kernels (stm_kernels_aggm.hip) on ragged shapes: W % 4 != 0 (partial pixel groups),
     D % 16 != 0 (padded chunks), D > 64 (several chunk sets), arms longer than the image, zd at the range edge, usd = 110 (the
