@@ -57,7 +57,8 @@ void        stm_set_error_mode(int mode);
 const char *stm_last_error(void);
 /* frees the cached device workspace (the reference cudaMalloc/cudaFree's per call) */
 void        stm_release_workspace(void);
-/* per-kernel HIP-event profiling of the dominant kernels inside the frame pipeline */
+/* per-kernel HIP-event profiling of the named kernels inside the frame pipeline: 0 off, 1 every named kernel,
+ * 2 the aggregation kernels only (three event pairs per frame: what bench.py keeps on inside its timed region) */
 void        stm_prof_enable(int on);
 void        stm_prof_reset(void);
 /* returns number of timed launches of `kernel` ("agg_h","agg_v","cost_init","agg_hw", ...) and their

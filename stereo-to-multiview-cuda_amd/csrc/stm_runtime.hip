@@ -147,8 +147,8 @@ struct ProfRec {
     std::string name;
     hipEvent_t a, b;
 };
-static bool g_prof_on = false;
-bool prof_enabled() { return g_prof_on; }
+static int g_prof_on = 0; // 0 off, 1 every named kernel, 2 the aggregation kernels only (a few events per frame)
+bool prof_enabled() { return g_prof_on != 0; }
 static std::vector<ProfRec> g_prof;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 static std::mutex g_prof_mu; // host threads may drive the library concurrently (stm_hip.h)
@@ -156,6 +156,7 @@ static std::mutex g_prof_mu; // host threads may drive the library concurrently 
 ProfScope::ProfScope(const char *name) : slot(-1)
 {
     if (!g_prof_on) return;
+    if (g_prof_on == 2 && strncmp(name, "pq_", 3) != 0 && strncmp(name, "agg_", 4) != 0 && strcmp(name, "cost_init") != 0) return;
     ProfRec r;
     r.name = name;
     std::lock_guard<std::mutex> lock(g_prof_mu);
@@ -243,7 +244,7 @@ void *stm_get_stream(void) { return (void *)stm::g_stream; }
 void stm_set_error_mode(int m) { stm::g_error_mode = m; }
 const char *stm_last_error(void) { return stm::g_last_error.c_str(); }
 void stm_release_workspace(void) { stm::ws_release(); }
-void stm_prof_enable(int on) { stm::g_prof_on = on != 0; }
+void stm_prof_enable(int on) { stm::g_prof_on = on < 0 ? 0 : on; }
 void stm_prof_reset(void)
 {
     std::lock_guard<std::mutex> lock(stm::g_prof_mu);

@@ -86,7 +86,8 @@ def d_dc_wta(cost_tab, disp, num_disp, zero_disp):
 
 
 def prof_enable(on=True):
-    lib().stm_prof_enable(1 if on else 0)
+    """True / 1: HIP events around every named kernel; 2: around the aggregation kernels only; False / 0: off."""
+    lib().stm_prof_enable(int(on))
 
 
 def prof_reset():
