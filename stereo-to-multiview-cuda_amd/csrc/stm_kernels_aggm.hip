@@ -6,32 +6,34 @@
 //   ca_cross_vhsum_kernel_2       d_ca_cross_sum.cu:148-198   (vertical window sum; the two transposes are deleted)
 //   dc_wta_kernel                 d_dc_wta.cu:9-35
 //
-// Why the matrix pipe, when the path has no dense contraction: the reference sums every window element by element in
+// Why MFMA instructions, when the path has no dense contraction: the reference sums every window element by element in
 // float32, ascending (d_ca_cross_sum.cu:284-289), and WTA indices must be bit-exact, so the summation ORDER is fixed and
-// a prefix-sum formulation is ruled out (hard part 1).  v_mfma_f32_4x4x1_16B_f32 computes, for each of
-// 16 blocks, D[i][j] = A[i] * B[j] + C[i][j] with ONE product per output (K = 1): with A in {0, 1} that is exactly
-// "acc = acc + b" (or "acc = acc", 0 * b = +0 for finite b), one float32 rounding per step -- the reference's chain.
-// tools/mfma_probe.hip verifies on hardware: register layout, bit-exactness of a 96-step masked chain, the CBSZ/ABID
-// broadcast.  One instruction adds one window element to 4 pixels x 64 hypotheses (256 adds per 8 cycles per SIMD, the
-// full fp32 rate), and each LDS value feeds 4 pixels instead of 1: the LDS traffic that bounds stm_k_agg_h / stm_k_agg_v
-//  drops 4x and no lane idles while a neighbour's longer window finishes.
+// a prefix-sum formulation is ruled out (hard part 1).  v_mfma_f32_16x16x1_4B_f32 computes, for each of
+// 4 blocks, D[m][n] = A[m] * B[n] + C[m][n] with ONE product per output (K = 1): with A in {0, 1} that is exactly
+// "acc = acc + b" (or "acc = acc", 0 * b = +0 for finite b), one float32 rounding per step -- the reference's chain, for 16
+// pixels x 16 hypotheses x 4 blocks per instruction, fed by ONE LDS value per hypothesis instead of one per pixel.
+// tools/mfma_probe*.hip verify on hardware: register layouts, bit-exactness of a 96-step masked chain, the CBSZ/ABID
+// broadcast, and that f32 MFMAs occupy the SIMD's vector ALU (their time adds to the VALU time: 43 cycles per instruction in
+// these dependent chains) -- what is bought is not a second pipe but 1024 exact adds per issue slot, 16x less LDS traffic
+// than stm_k_agg_h / stm_k_agg_v and no lane idling behind a neighbour's longer window.
 //
-// Roles.  B operand = costs: lane l of block b = l / 4 supplies B[j = l % 4].  A operand = window masks: with CBSZ = 2
-// the A values of block (4 * (b / 4) + ABID) are broadcast to the 4 blocks of each group, so ONE mask register per lane
-// holds the masks of four consecutive steps (block b % 4 = step) and ABID = 0..3 selects the step: 3 VALU instructions
-// per 4 steps.  Result: register i of lane 4b + j = out[pixel i][hypothesis j of block b].
+// Horizontal kernels: block b of the instruction = chunk of 16 hypotheses; A[m] = window mask of pixel m (CBSZ = 2: the A
+// values of block ABID serve all four blocks, so ONE mask register holds the masks of four consecutive steps and ABID
+// selects the step: 3 VALU instructions per 4 steps); B[n] = cost of hypothesis n (lane 16 b + n).
+// Vertical kernel: block b = image column; A[m] = window mask of (row m, column b); B[n] = cost of hypothesis n at the
+// current window row.  D: register 4 b + i of lane 16 q + n = out[pixel or row 4 q + i][block b][hypothesis n].
 //
 // Volume layout inside the frame pipeline ("PQ"): float4 [chunk = d / 16][y][g = x / 4][dd = d % 16], the float4 = the four
 // pixels 4g..4g+3 of one hypothesis.  Horizontal pass: a lane reads one float4 = four consecutive window steps of its
-// hypothesis; vertical pass: a lane reads one float4 per row = the same step of four column chains.  Every global access
-// of a wave is 16 B per lane, 256 B contiguous per 16 lanes, 1 KB contiguous per wave in the horizontal kernels.
+// hypothesis; vertical pass: the four columns of a float4 are the four blocks (the LDS rings hold a row as float
+// [4 columns][16 hypotheses], which lane 16 b + n reads linearly).  Every global access of a wave is 16 B per lane, 256 B
+// contiguous per 16 lanes, 1 KB contiguous per wave in the horizontal kernels.
 #include "stm_common.h"
 
 namespace stm {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-#define STM_MFMA(m, b, acc, abid) __builtin_amdgcn_mfma_f32_4x4x1f32(m, b, acc, 2, abid, 0)
 #define STM_MFMA16(m, b, acc, abid) __builtin_amdgcn_mfma_f32_16x16x1f32(m, b, acc, 2, abid, 0)
 typedef float f16v __attribute__((ext_vector_type(16)));
 
