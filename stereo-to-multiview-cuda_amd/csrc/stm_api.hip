@@ -296,7 +296,7 @@ void stm_d_dc_hslo(float **d_cost, float *d_disp, unsigned char *d_img_l, unsign
     const u8 *ia[1] = {d_img_l}, *ib[1] = {d_img_r};
     const int os[1] = {1};
     float *dv[1] = {d_disp};
-    launch_hslo_wta(1, &c, ia, ib, os, dv, nullptr, T, H1, H2, num_disp, zero_disp, num_rows, num_cols, elem_sz);
+    launch_hslo_wta(1, &c, ia, ib, os, dv, T, H1, H2, num_disp, zero_disp, num_rows, num_cols, elem_sz);
 }
 void stm_dc_hslo(float **cost, float *disp, unsigned char *img_l, unsigned char *img_r, float T, float H1, float H2,
                  int num_disp, int zero_disp, int num_rows, int num_cols, int elem_sz)
@@ -313,7 +313,7 @@ void stm_dc_hslo(float **cost, float *disp, unsigned char *img_l, unsigned char 
     const u8 *ia[1] = {dl}, *ib[1] = {dr};
     const int os[1] = {1};
     float *dv[1] = {d};
-    launch_hslo_wta(1, &cv, ia, ib, os, dv, nullptr, T, H1, H2, num_disp, zero_disp, num_rows, num_cols, elem_sz);
+    launch_hslo_wta(1, &cv, ia, ib, os, dv, T, H1, H2, num_disp, zero_disp, num_rows, num_cols, elem_sz);
     down(disp, d, HW);
     sync();
 }
@@ -638,15 +638,16 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
     const size_t HW = (size_t)H * W;
     const int NQ = (D + 3) / 4;
     const size_t V = HW * NQ * 4; // volumes are kept quad-interleaved (float4 [NQ][H][W]) inside the frame
-    const bool matrix_pipe = !hslo && (agg_variant() / 10000) % 10 != 1 && aggm_supports(usd); // default aggregation path: stm_kernels_aggm.hip
+    const bool matrix_pipe = (agg_variant() / 10000) % 10 != 1 && aggm_supports(usd); // default aggregation path: stm_kernels_aggm.hip
     float *cost = matrix_pipe ? nullptr : Workspace::get<float>(2 * V), *scratch = matrix_pipe ? nullptr : Workspace::get<float>(V);
     uint32_t *pk_l = pre ? pre[0] : Workspace::get<uint32_t>(HW), *pk_r = pre ? pre[1] : Workspace::get<uint32_t>(HW);
     Vol cl = vol_quads(cost, HW), cr = vol_quads(cost ? cost + V : nullptr, HW), sc = vol_quads(scratch, HW);
-    // without HSLO the first aggregation pass computes the initial costs itself (stm_k_agg_h COST mode) and the 2 V of
-    // initial costs are never written; the HSLO path and the per-stage API materialise them with stm_k_cost_init
+    // the first aggregation pass computes the initial costs itself (COST mode) and the 2 V of initial costs are never
+    // written; only HSLO on the vector-ALU path and the per-stage API materialise them with stm_k_cost_init
+    const bool cost_volume = hslo && !matrix_pipe;
     uint32_t *cen[2] = {nullptr, nullptr};
     core_ci(img_l, img_r, cl, cr, pk_l, pk_r, ad_coeff, census_coeff, D, zero_disp, H, W, elem_sz, pre != nullptr,
-            hslo ? nullptr : cen);
+            cost_volume ? nullptr : cen);
 
     al = carve_arms(HW);
     ar = carve_arms(HW);
@@ -658,25 +659,27 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
     }
     // with refinement the raw WTA maps live in scratch and the bilateral filter, the last step, writes the caller's buffers
     float *wl = refine ? Workspace::get<float>(HW) : d_disp_l, *wr = refine ? Workspace::get<float>(HW) : d_disp_r;
-    if (hslo) {
-        // Mei et al. 3.3: scanline optimisation of the aggregated cost, then WTA.  Penalty constants: the values the
-        // reference's (commented-out) test call uses, image_io.cpp:311-313.  Parity unpinned.
-        core_agg(cl, sc, al, D, H, W, usd);
-        core_agg(cr, sc, ar, D, H, W, usd);
-        const Vol cv[2] = {cl, cr};
-        const u8 *ia[2] = {img_l, img_r}, *ib[2] = {img_r, img_l}; // the right view's own image plays "left"
-        const int os[2] = {1, -1};
-        float *dv[2] = {wl, wr};
-        launch_hslo_wta(2, cv, ia, ib, os, dv, nullptr, 15.0f, 1.0f, 3.0f, D, zero_disp, H, W, elem_sz);
-    } else if (matrix_pipe) {
-        // the aggregation kernels on the matrix pipe: cost -> H -> V, V -> H + WTA, two PQ-layout volumes per view
+    // HSLO = Mei et al. 3.3: scanline optimisation of the aggregated cost, then WTA.  Penalty constants: the values the
+    // reference's (commented-out) test call uses, image_io.cpp:311-313.  Parity unpinned.
+    const u8 *hs_a[2] = {img_l, img_r}, *hs_b[2] = {img_r, img_l}; // the right view's own image plays "left"
+    const int hs_sign[2] = {1, -1};
+    if (matrix_pipe) {
+        // the aggregation kernels on the matrix pipe: cost -> H -> V, V -> H (+ WTA, or + the HSLO passes on the volume), two
+        // PQ-layout volumes per view
         const size_t VP = pq_volume_floats(D, H, W);
         float *m = Workspace::get<float>(4 * VP);
         float *va[2] = {m, m + VP}, *vb[2] = {m + 2 * VP, m + 3 * VP};
         const uint32_t *pk[2] = {pk_l, pk_r}, *cn[2] = {cen[0], cen[1]};
         const u8 *u[2] = {al.up, ar.up}, *d[2] = {al.down, ar.down}, *l[2] = {al.left, ar.left}, *r[2] = {al.right, ar.right};
         float *dv[2] = {wl, wr};
-        launch_aggm_frame(pk, cn, rho_table(ad_coeff, census_coeff), va, vb, u, d, l, r, dv, D, zero_disp, H, W, usd);
+        launch_aggm_frame(pk, cn, rho_table(ad_coeff, census_coeff), va, vb, u, d, l, r, dv, D, zero_disp, H, W, usd, hslo);
+        if (hslo) launch_hslo_wta_pq(2, vb, va, hs_a, hs_b, hs_sign, dv, 15.0f, 1.0f, 3.0f, D, zero_disp, H, W, elem_sz);
+    } else if (hslo) {
+        core_agg(cl, sc, al, D, H, W, usd);
+        core_agg(cr, sc, ar, D, H, W, usd);
+        const Vol cv[2] = {cl, cr};
+        float *dv[2] = {wl, wr};
+        launch_hslo_wta(2, cv, hs_a, hs_b, hs_sign, dv, 15.0f, 1.0f, 3.0f, D, zero_disp, H, W, elem_sz);
     } else {
         // legacy (stm_set_agg_variant(10000)): H, V, V per view on the vector ALU, then the last H pass + WTA of both views in one launch.  After three passes a view's
         // data sits in its scratch volume; the right view uses the left view's (now free) cost volume as scratch.

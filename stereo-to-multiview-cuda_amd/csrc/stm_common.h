@@ -178,11 +178,13 @@ size_t pq_volume_floats(int D, int H, int W);
 bool aggm_supports(int usd);
 void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, const float *lut, float *const *vol_a, float *const *vol_b,
                        const u8 *const *armU, const u8 *const *armD, const u8 *const *armL, const u8 *const *armR, float *const *disp,
-                       int D, int zd, int H, int W, int usd);
+                       int D, int zd, int H, int W, int usd, bool keep_volume = false);
 // HSLO (stm_kernels_hslo.hip)
 void launch_hslo_wta(int nviews, const Vol *cost, const u8 *const *img_a, const u8 *const *img_b, const int *osign,
-                     float *const *disp, float *const *vol_out, float T, float H1, float H2, int D, int zd, int H, int W,
-                     int elem_sz);
+                     float *const *disp, float T, float H1, float H2, int D, int zd, int H, int W, int elem_sz);
+// the same on PQ volumes (the frame pipeline): cost_pq read only, acc_pq scratch of the same size
+void launch_hslo_wta_pq(int nviews, float *const *cost_pq, float *const *acc_pq, const u8 *const *img_a, const u8 *const *img_b,
+                        const int *osign, float *const *disp, float T, float H1, float H2, int D, int zd, int H, int W, int elem_sz);
 
 // host-built tables (same formulas as the reference's host code; see stm_tables.cpp)
 void rho_luts(float ad_coeff, float census_coeff, float *lut_ad /*766*/, float *lut_census /*65*/);

@@ -542,9 +542,10 @@ static size_t v12_smem(int usd, int ntp)
 bool aggm_supports(int usd) { return usd >= 1 && v12_smem(usd > 255 ? 255 : usd, 3) <= 160 * 1024; }
 
 // cost -> H -> V, V -> H + WTA for both views of a frame.  vol_a / vol_b: two PQ volumes per view (pq_volume_floats each).
+// keep_volume: the last pass writes the aggregated costs to vol_b instead of doing WTA (the HSLO stage follows; disp unused).
 void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, const float *lut, float *const *vol_a, float *const *vol_b,
                        const u8 *const *armU, const u8 *const *armD, const u8 *const *armL, const u8 *const *armR, float *const *disp,
-                       int D, int zd, int H, int W, int usd)
+                       int D, int zd, int H, int W, int usd, bool keep_volume)
 {
     PQViews v;
     for (int i = 0; i < 2; ++i) {
@@ -603,8 +604,13 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
     }
     {
         ProfScope p("pq_hw");
-        allow_lds_m((const void *)stm_k_pq_h<NW, true, false>, smem_h);
-        STM_LAUNCH((stm_k_pq_h<NW, true, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, 0);
+        if (keep_volume) {
+            allow_lds_m((const void *)stm_k_pq_h<NW, false, false>, smem_h);
+            STM_LAUNCH((stm_k_pq_h<NW, false, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, 0);
+        } else {
+            allow_lds_m((const void *)stm_k_pq_h<NW, true, false>, smem_h);
+            STM_LAUNCH((stm_k_pq_h<NW, true, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, 0);
+        }
         STM_CHECK_LAUNCH();
     }
 }

@@ -129,6 +129,15 @@ __device__ __forceinline__ int16_t irv_code(u8 outl, float disp, int zd, int nb)
     return (b >= 0 && b < nb) ? (int16_t)b : (int16_t)-2;
 }
 
+// counters + dirty bytes of a frame.  A kernel rather than hipMemsetAsync: inside a captured frame (stm_stream.hip) this
+// was the only memset node of the graph, and the replayed graph did not always order it before the compaction that
+// follows (the counters then grow from frame to frame and the vote walks off the end of the list)
+__global__ __launch_bounds__(256) void stm_k_irv_clear(int *__restrict__ words, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) words[i] = 0;
+}
+
 // four pixels per thread (one dword of the u8 outlier map), 4096 pixels per block; the block's outliers are
 // appended in raster order with ONE global atomic (the counter is a single address: per-wave atomics made this
 // kernel atomic-bound)
@@ -358,7 +367,8 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
     const int tiles_x = cdiv(W, IV_TILE), tiles_y = cdiv(H, IV_TILE);
     const size_t dirty_sz = (size_t)(rounds + 1) * tiles_x * tiles_y;
     const size_t ncount = 4; // per view: list length
-    int *counts = Workspace::get<int>(ncount + (2 * dirty_sz + 3) / 4); // counters, then dirty bytes: one memset
+    const size_t nwords = ncount + (2 * dirty_sz + 3) / 4;
+    int *counts = Workspace::get<int>(nwords); // counters, then dirty bytes: cleared together
     for (int v = 0; v < 2; ++v) {
         const int s = v < nviews ? v : 0;
         a.disp[v] = disp[s]; a.outl[v] = outl[s];
@@ -378,7 +388,8 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
         return;
     }
     ProfScope p("irv");
-    STM_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * ncount + 2 * dirty_sz, stream()));
+    STM_LAUNCH(stm_k_irv_clear, dim3((unsigned)cdiv((int)nwords, 256)), dim3(256), 0, stream(), counts, (int)nwords);
+    STM_CHECK_LAUNCH();
     STM_LAUNCH(stm_k_irv_compact, dim3((unsigned)((HW + 4 * IC_T - 1) / (4 * IC_T)), nviews), dim3(IC_T), 0, stream(), a, (uint32_t)HW, zd,
                        nb);
     STM_CHECK_LAUNCH();
