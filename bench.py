@@ -178,7 +178,7 @@ def main():
     timed(nbreak, 1)
     other = {}
     if rank == 0:
-        for name in AGG_KERNELS + ("cross_arms", "hslo_classes", "hslo_h", "hslo_v", "hslo_to_pq", "wta", "irv", "bilateral", "gaussian_max", "view_synth", "mux"):
+        for name in AGG_KERNELS + ("cross_arms", "hslo_classes", "hslo_lr", "hslo_rl", "hslo_tb", "hslo_bt", "hslo_to_pq", "wta", "irv", "bilateral", "gaussian_max", "view_synth", "mux"):
             n, ms = dev.prof_read(name)
             if n:
                 other[name] = ms / n

@@ -211,7 +211,7 @@ __device__ __forceinline__ float2 penalties(const float2 *ptab, uint32_t c2w, in
 // grid (cdiv(H, 4), views); block = 4 waves, one image row each.  BWD = false: left->right, acc = C_lr;
 // BWD = true: right->left, acc += C_rl.  PF = groups of four pixels loaded ahead of the walk.
 template <int DPL, bool BWD, int PF>
-__global__ __launch_bounds__(256) void stm_k_hslo_h(HsloArgs a, int D, int zd, int H, int W, int G, int WU, int WP, int PAD)
+__global__ __launch_bounds__(256) void stm_k_hslo_h(HsloArgs a, int D, int zd, int H, int W, int G, int WU, int WP, int PAD, int dbg)
 {
     __shared__ float2 ptab[9];
     if (threadIdx.x < 9) ptab[threadIdx.x] = make_float2(a.p1[threadIdx.x], a.p2[threadIdx.x]);
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void stm_k_hslo_h(HsloArgs a, int D, int zd, i
             float cc[DPL], cur[DPL];
 #pragma unroll
             for (int j = 0; j < DPL; ++j) cc[j] = r.c[j][k];
-            if (x == x_first) { // first pixel of the line: Cr(p0, d) = C(p0, d)
+            if (x == x_first || (dbg & 1)) { // first pixel of the line: Cr(p0, d) = C(p0, d)
 #pragma unroll
                 for (int j = 0; j < DPL; ++j) cur[j] = cc[j];
             } else {
@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256) void stm_k_hslo_h(HsloArgs a, int D, int zd, i
             }
         }
 #pragma unroll
-        for (int j = 0; j < DPL; ++j) nt_store4(ap[j] + (size_t)g * gs[j], o[j]);
+        for (int j = 0; j < DPL; ++j)
+            if (!(dbg & 2)) nt_store4(ap[j] + (size_t)g * gs[j], o[j]);
     };
 
     Row buf[PF];
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void stm_k_hslo_h(HsloArgs a, int D, int zd, i
 // grid (cdiv(G, 4), views); block = 4 waves, one group of four columns each (adjacent groups: 1 KB contiguous per row and
 // chunk).  BWD = false: top->bottom, acc += C_tb;  BWD = true: bottom->top, ((acc + C_bt) * 0.25) -> WTA -> disp.
 template <int DPL, bool BWD, int PF>
-__global__ __launch_bounds__(256) void stm_k_hslo_v(HsloArgs a, int D, int zd, int H, int W, int G, int WU, int WP, int PAD)
+__global__ __launch_bounds__(256) void stm_k_hslo_v(HsloArgs a, int D, int zd, int H, int W, int G, int WU, int WP, int PAD, int dbg)
 {
     __shared__ float2 ptab[9];
     if (threadIdx.x < 9) ptab[threadIdx.x] = make_float2(a.p1[threadIdx.x], a.p2[threadIdx.x]);
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void stm_k_hslo_v(HsloArgs a, int D, int zd, i
     auto process = [&](const Row &r, int v) {
         const int y = BWD ? H - 1 - v : v;
         float cur[4][DPL];
-        if (v == 0) { // first pixel of the four lines
+        if (v == 0 || (dbg & 1)) { // first pixel of the four lines
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -392,28 +393,35 @@ __global__ __launch_bounds__(256) void stm_k_hslo_v(HsloArgs a, int D, int zd, i
                 f4 o;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = r.s[j][k] + cur[k][j];
-                nt_store4(ap[j] + (size_t)y * rs[j], o);
+                if (!(dbg & 2)) nt_store4(ap[j] + (size_t)y * rs[j], o);
             }
         } else {
-            // C2(p, d) = (((C_lr + C_rl) + C_tb) + C_bt) * 0.25f, then first-lowest-wins WTA (d_dc_wta.cu:19-34): the lane's best
-            // (ascending d, strict <), the wave minimum, then the smallest d among the lanes that hold it
+            // C2(p, d) = (((C_lr + C_rl) + C_tb) + C_bt) * 0.25f, then first-lowest-wins WTA (d_dc_wta.cu:19-34).  The scaling
+            // by 0.25 is exact and order-preserving, so the argmin is taken on the unscaled sums: the lane's best (ascending d,
+            // strict <), the wave minimum, then the smallest d among the lanes that hold it (with one hypothesis per lane that
+            // is the first set bit of the equality ballot)
             float bv[4], bd[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                bv[k] = (r.s[0][k] + cur[k][0]) * 0.25f;
+                bv[k] = r.s[0][k] + cur[k][0];
                 bd[k] = (float)lane;
 #pragma unroll
                 for (int j = 1; j < DPL; ++j) {
-                    const float val = (r.s[j][k] + cur[k][j]) * 0.25f;
+                    const float val = r.s[j][k] + cur[k][j];
                     if (val < bv[k]) { bv[k] = val; bd[k] = (float)(lane + 64 * j); }
                 }
             }
             float mv[4] = {bv[0], bv[1], bv[2], bv[3]};
             wave_min4(mv);
             float cd[4];
+            if (DPL == 1) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cd[k] = bv[k] == mv[k] ? bd[k] : 1.0e9f;
-            wave_min4(cd);
+                for (int k = 0; k < 4; ++k) cd[k] = (float)__builtin_ctzll(__ballot(bv[k] == mv[k]));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cd[k] = bv[k] == mv[k] ? bd[k] : 1.0e9f;
+                wave_min4(cd);
+            }
             if (lane < 4 && 4 * g + lane < W) {
                 const float best = lane == 0 ? cd[0] : (lane == 1 ? cd[1] : (lane == 2 ? cd[2] : cd[3]));
                 disp[(size_t)y * W + 4 * g + lane] = best - (float)zd;
@@ -436,18 +444,25 @@ __global__ __launch_bounds__(256) void stm_k_hslo_v(HsloArgs a, int D, int zd, i
 template <int DPL, int PF>
 void hslo_passes(const HsloArgs &a, int nviews, int D, int zd, int H, int W, int G, int WU, int WP, int PAD)
 {
+    const int dbg = (agg_variant() / 100000) % 10; // timing experiments only (stm_hip.h): 1 = no recurrence, 2 = no stores
     {
-        ProfScope p("hslo_h");
-        STM_LAUNCH((stm_k_hslo_h<DPL, false, PF>), dim3(cdiv(H, 4), nviews), dim3(256), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD);
-        STM_CHECK_LAUNCH();
-        STM_LAUNCH((stm_k_hslo_h<DPL, true, PF>), dim3(cdiv(H, 4), nviews), dim3(256), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD);
+        ProfScope p("hslo_lr");
+        STM_LAUNCH((stm_k_hslo_h<DPL, false, PF>), dim3(cdiv(H, 4), nviews), dim3(256), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD, dbg);
         STM_CHECK_LAUNCH();
     }
     {
-        ProfScope p("hslo_v");
-        STM_LAUNCH((stm_k_hslo_v<DPL, false, PF>), dim3(cdiv(G, 4), nviews), dim3(256), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD);
+        ProfScope p("hslo_rl");
+        STM_LAUNCH((stm_k_hslo_h<DPL, true, PF>), dim3(cdiv(H, 4), nviews), dim3(256), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD, dbg);
         STM_CHECK_LAUNCH();
-        STM_LAUNCH((stm_k_hslo_v<DPL, true, PF>), dim3(cdiv(G, 4), nviews), dim3(256), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD);
+    }
+    {
+        ProfScope p("hslo_tb");
+        STM_LAUNCH((stm_k_hslo_v<DPL, false, PF>), dim3(cdiv(G, 4), nviews), dim3(256), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD, dbg);
+        STM_CHECK_LAUNCH();
+    }
+    {
+        ProfScope p("hslo_bt");
+        STM_LAUNCH((stm_k_hslo_v<DPL, true, PF>), dim3(cdiv(G, 4), nviews), dim3(256), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD, dbg);
         STM_CHECK_LAUNCH();
     }
 }

@@ -5,7 +5,7 @@ import collections, csv, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("stm::", "")
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("stm::", "")
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(acc):
     if "stm_k_" not in k: continue
