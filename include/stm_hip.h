@@ -61,14 +61,15 @@ void        stm_release_workspace(void);
  * 2 the aggregation kernels only (three event pairs per frame: what bench.py keeps on inside its timed region) */
 void        stm_prof_enable(int on);
 void        stm_prof_reset(void);
-/* returns number of timed launches of `kernel` ("agg_h","agg_v","cost_init","agg_hw", ...) and their
+/* returns number of timed launches of `kernel` ("pq_h","pq_v12","pq_hw","cross_arms","irv","hslo_lr","hslo_rl","hslo_tb",
+ * "hslo_bt", ...) and their
  * summed duration in ms; synchronises the recorded events. */
 int         stm_prof_read(const char *kernel, float *total_ms);
 /* aggregation variant of the frame pipeline (0 = default: matrix-pipe kernels, stm_kernels_aggm.hip); decimal digits, used by
  * the benchmark and the tools to A/B variants in one process: 10000 = vector-ALU aggregation kernels (stm_kernels_agg.hip; the
  * low digits then select their tunables), 1000000 = separate initial-cost kernel instead of computing the costs inside the
  * first pass, N0000000 (N = 1..4) = N row tiles per pass and step in the fused vertical kernel, N00000 = timing experiments
- * (results are NOT valid: parts of the kernels are skipped) */
+ * (results are NOT valid: parts of the kernels are skipped; in the HSLO passes 1 = no recurrence, 2 = no volume stores) */
 void        stm_set_agg_variant(int v);
 
 /* ------------------------------------------------------- cost init (a1-a7) */

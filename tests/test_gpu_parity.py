@@ -590,6 +590,55 @@ def test_hslo_wave_per_line(api, orc, D, zd):
     assert np.array_equal(api.dc_hslo(c, L, R, 15.0, 1.0, 3.0, zd), orc.dc_hslo(c, L, R, 15.0, 1.0, 3.0, zd))
 
 
+@pytest.mark.parametrize("H,W,D,zd", [(1, 1, 1, 0), (1, 9, 4, 0), (2, 3, 7, 6), (7, 2, 16, 8), (5, 5, 17, 0), (9, 13, 65, 64),
+                                      (6, 11, 129, 3), (4, 6, 256, 128), (33, 31, 48, 47)])
+def test_hslo_ragged_shapes(api, orc, H, W, D, zd):
+    """Group (4-pixel) and chunk (16-hypothesis) remainders, single rows / columns, zero_disp at either end of the range:
+    the lanes of absent hypotheses hold +inf, the last group is partly outside the image."""
+    L, R = rand_pair(H, W, 1000 + 7 * H + W)
+    rng = np.random.RandomState(D + W)
+    c = (rng.random_sample((D, H, W)) * 3).astype(np.float32)
+    assert np.array_equal(api.dc_hslo(c, L, R, 15.0, 1.0, 3.0, zd), orc.dc_hslo(c, L, R, 15.0, 1.0, 3.0, zd))
+
+
+def test_hslo_steps_on_the_threshold(api, orc):
+    """Colour steps of exactly T fall in neither '<' nor '>' (third penalty class, d_dc_hslo.cu:73-93): grey images whose
+    neighbouring pixels differ by 0, 15 or 30 hit all nine (class D1, class D2) combinations."""
+    H, W, D, zd = 24, 40, 12, 5
+    rng = np.random.RandomState(5)
+    def steps():
+        g = 60 + 15 * rng.randint(0, 3, size=(H, W))
+        return np.repeat(g[:, :, None], 3, axis=2).astype(np.uint8)
+    L, R = steps(), steps()
+    c = (rng.random_sample((D, H, W)) * 3).astype(np.float32)
+    assert np.array_equal(api.dc_hslo(c, L, R, 15.0, 1.0, 3.0, zd), orc.dc_hslo(c, L, R, 15.0, 1.0, 3.0, zd))
+
+
+@pytest.mark.parametrize("variant", [0, 10000])
+def test_device_frame_with_hslo_ragged_width(gpu_ready, orc, variant):
+    """A frame whose width is not a multiple of four, on the matrix-pipe aggregation (PQ volumes handed straight to the
+    scanline passes) and on the vector-ALU aggregation (quads volumes converted first)."""
+    import torch
+    import stm_amd
+    from stm_amd import device_api as dev, synth
+    H, W, D, zd = 37, 203, 20, 7
+    sbs, _ = synth.sbs_frame(H, W, D, zd)
+    p = dev.FrameParams(num_disp=D, zero_disp=zd, usd=11, lsd=5)
+    dl = torch.zeros(H, W, dtype=torch.float32, device="cuda")
+    dr = torch.zeros_like(dl)
+    out = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+    stm_amd.lib().stm_set_agg_variant(variant)
+    try:
+        dev.d_adcensus_stm(torch.from_numpy(sbs).cuda(), dl, dr, out, p, stages=3 | 0x100)
+        torch.cuda.synchronize()
+    finally:
+        stm_amd.lib().stm_set_agg_variant(0)
+    want = orc.adcensus_stm(sbs, H, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd, p.usd,
+                            p.lsd, p.thresh_s, p.thresh_h, hslo=True)
+    assert np.array_equal(dl.cpu().numpy(), want["disp_l"]) and np.array_equal(dr.cpu().numpy(), want["disp_r"])
+    assert np.array_equal(out.cpu().numpy(), want["interlaced"])
+
+
 @pytest.mark.parametrize("stages", [1, 3])
 def test_device_frame_pipeline_with_hslo(gpu_ready, orc, stages):
     """BASELINE config 3 ordering: aggregation -> scanline optimisation -> WTA -> DCC/IRV/bilateral (stages | 0x100)."""
