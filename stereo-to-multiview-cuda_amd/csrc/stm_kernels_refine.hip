@@ -200,9 +200,10 @@ constexpr int IV_U = 4;         // row pairs whose loads are in flight together
 // one LDS atomic per voting lane.  Merging equal bins with ballots first was measured slower in both forms tried
 // (unbounded merge loop, and two merge rounds + per-lane fallback): the kernel is instruction-issue bound, not
 // bound by same-address serialisation inside the LDS atomic unit.
-__device__ __forceinline__ void irv_tally(int code, uint32_t *hist, int &total)
+// `seen` counts, per lane, the region pixels that are not outliers (code != -1); the wave total is formed once per outlier
+__device__ __forceinline__ void irv_tally(int code, uint32_t *hist, int &seen)
 {
-    total += __popcll(__ballot(code != -1));
+    seen += code != -1;
     if (code >= 0) atomicAdd(&hist[code], 1u);
 }
 
@@ -270,55 +271,57 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
         __builtin_amdgcn_wave_barrier();
         const int nrows = cu + cd + 1; // rows gy-cu .. gy+cd inclusive (SURVEY A-Q17 iii)
         const int y_top = gy - cu;
-        int total = 0;
+        int seen = 0;
         for (int jb = 0; jb < nrows; jb += 128) { // 128 rows per outer step covers every usd <= 63 in one go
-            // horizontal arms of the region's rows, fetched once and packed into one register per 64 rows:
-            // armL in the low byte, segment width armL + armR + 1 (<= 511) above it
-            uint32_t packed = 0;
-            uint32_t packed_hi = 0;
-            if (jb + lane < nrows) {
-                const int q = (y_top + jb + lane) * W + gx;
-                const uint32_t cl = aL[q];
-                packed = cl | ((cl + (uint32_t)aR[q] + 1u) << 8);
-            }
-            if (jb + 64 + lane < nrows) {
-                const int q = (y_top + jb + 64 + lane) * W + gx;
-                const uint32_t cl = aL[q];
-                packed_hi = cl | ((cl + (uint32_t)aR[q] + 1u) << 8);
-            }
-            const int jend = min(nrows - jb, 128);
-            for (int j0 = 0; j0 < jend; j0 += IV_U) {
-                int cdv[IV_U], wd[IV_U], base[IV_U];
-                int wmax = 0;
+            // horizontal arms of the region's rows, fetched once and packed into one register per 64 rows: armL in the low byte,
+            // segment width armL + armR + 1 (<= 511) above it -- both already clamped into the image row (a no-op for consistent
+            // arms), so that the per-row scalar work is an unpack and an add: the kernel is bound by scalar-ALU issue
+            uint32_t packed[2] = {0, 0};
 #pragma unroll
-                for (int u = 0; u < IV_U; ++u) { // first 64 pixels of IV_U rows: all loads issued before any is consumed
-                    const int j = j0 + u; // wave-uniform
-                    const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)((j & 64) ? packed_hi : packed), j & 63);
-                    const int cl = (int)(pk & 0xff);
-                    int w = j < jend ? (int)(pk >> 8) : 0;
-                    int xs = gx - cl; // scalar; clamp the segment into the row (no-op for consistent arms)
-                    if (xs < 0) { w += xs; xs = 0; }
-                    w = min(w, W - xs);
-                    wd[u] = w;
-                    wmax = max(wmax, w);
-                    base[u] = (y_top + jb + j) * W + xs;
-                    cdv[u] = -1; // -1: no vote (outside the row segment, or an outlier itself)
-                    if (lane < w) cdv[u] = (code_pl + (uint32_t)base[u])[(uint32_t)lane]; // scalar row pointer + loop-invariant lane offset
+            for (int h = 0; h < 2; ++h)
+                if (jb + 64 * h + lane < nrows) {
+                    const int q = (y_top + jb + 64 * h + lane) * W + gx;
+                    const int cl = min((int)aL[q], gx);
+                    const int w = max(min(cl + (int)aR[q] + 1, W - (gx - cl)), 0);
+                    packed[h] = (uint32_t)cl | ((uint32_t)w << 8);
                 }
 #pragma unroll
-                for (int u = 0; u < IV_U; ++u) irv_tally(cdv[u], hist, total);
-                if (wmax > 64) { // segments wider than 64 pixels (arm sum >= 64): rare
+            for (int h = 0; h < 2; ++h) {
+                const int jend = min(nrows - jb - 64 * h, 64); // wave-uniform
+                if (jend <= 0) break;
+                const uint32_t src = packed[h]; // rows beyond the region hold 0: zero width, no load
+                int rb = (y_top + jb + 64 * h) * W + gx; // scalar: the anchor's column in the current row
+                for (int j0 = 0; j0 < jend; j0 += IV_U) {
+                    int cdv[IV_U], wd[IV_U], base[IV_U];
+                    int wmax = 0;
 #pragma unroll
-                    for (int u = 0; u < IV_U; ++u) {
-                        for (int c0 = 64; c0 < wd[u]; c0 += 64) {
-                            int code = -1;
-                            if (c0 + lane < wd[u]) code = code_pl[(uint32_t)base[u] + (uint32_t)(c0 + lane)];
-                            irv_tally(code, hist, total);
+                    for (int u = 0; u < IV_U; ++u) { // first 64 pixels of IV_U rows: all loads issued before any is consumed
+                        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)src, j0 + u);
+                        const int w = (int)(pk >> 8);
+                        wd[u] = w;
+                        wmax = max(wmax, w);
+                        base[u] = rb - (int)(pk & 0xff);
+                        rb += W;
+                        cdv[u] = -1; // -1: no vote (outside the row segment, or an outlier itself)
+                        if (lane < w) cdv[u] = (code_pl + (uint32_t)base[u])[(uint32_t)lane]; // scalar row pointer + loop-invariant lane offset
+                    }
+#pragma unroll
+                    for (int u = 0; u < IV_U; ++u) irv_tally(cdv[u], hist, seen);
+                    if (wmax > 64) { // segments wider than 64 pixels (arm sum >= 64): rare
+#pragma unroll
+                        for (int u = 0; u < IV_U; ++u) {
+                            for (int c0 = 64; c0 < wd[u]; c0 += 64) {
+                                int code = -1;
+                                if (c0 + lane < wd[u]) code = code_pl[(uint32_t)base[u] + (uint32_t)(c0 + lane)];
+                                irv_tally(code, hist, seen);
+                            }
                         }
                     }
                 }
             }
         }
+        for (int o2 = 32; o2 >= 1; o2 >>= 1) seen += __shfl_xor(seen, o2);
+        const int total = __builtin_amdgcn_readfirstlane(seen);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // first bin with the strictly largest count (d_dr_irv.cu:206-215): max over (count, -bin)
