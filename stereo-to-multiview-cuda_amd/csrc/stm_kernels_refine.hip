@@ -200,11 +200,26 @@ constexpr int IV_U = 4;         // row pairs whose loads are in flight together
 // one LDS atomic per voting lane.  Merging equal bins with ballots first was measured slower in both forms tried
 // (unbounded merge loop, and two merge rounds + per-lane fallback): the kernel is instruction-issue bound, not
 // bound by same-address serialisation inside the LDS atomic unit.
-// `seen` counts, per lane, the region pixels that are not outliers (code != -1); the wave total is formed once per outlier
-__device__ __forceinline__ void irv_tally(int code, uint32_t *hist, int &seen)
+__device__ __forceinline__ void irv_tally(int code, uint32_t *hist, int &total)
 {
-    seen += code != -1;
+    total += __popcll(__ballot(code != -1));
     if (code >= 0) atomicAdd(&hist[code], 1u);
+}
+
+// max over the 64 lanes as a scalar, on the DPP path (six v_max_u32 with a DPP operand; max is idempotent, so lanes without
+// a source simply keep their value): the LDS round trips of a shuffle reduction are what this kernel cannot afford -- its
+// waves spend half their time in s_waitcnt
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // Iteration `it` (0-based): vote (dr_irv_pre_kernel, d_dr_irv.cu:134-220) and apply (dr_irv_kernel_3, :17-43) for
@@ -271,7 +286,7 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
         __builtin_amdgcn_wave_barrier();
         const int nrows = cu + cd + 1; // rows gy-cu .. gy+cd inclusive (SURVEY A-Q17 iii)
         const int y_top = gy - cu;
-        int seen = 0;
+        int total = 0;
         for (int jb = 0; jb < nrows; jb += 128) { // 128 rows per outer step covers every usd <= 63 in one go
             // horizontal arms of the region's rows, fetched once and packed into one register per 64 rows: armL in the low byte,
             // segment width armL + armR + 1 (<= 511) above it -- both already clamped into the image row (a no-op for consistent
@@ -306,22 +321,20 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
                         if (lane < w) cdv[u] = (code_pl + (uint32_t)base[u])[(uint32_t)lane]; // scalar row pointer + loop-invariant lane offset
                     }
 #pragma unroll
-                    for (int u = 0; u < IV_U; ++u) irv_tally(cdv[u], hist, seen);
+                    for (int u = 0; u < IV_U; ++u) irv_tally(cdv[u], hist, total);
                     if (wmax > 64) { // segments wider than 64 pixels (arm sum >= 64): rare
 #pragma unroll
                         for (int u = 0; u < IV_U; ++u) {
                             for (int c0 = 64; c0 < wd[u]; c0 += 64) {
                                 int code = -1;
                                 if (c0 + lane < wd[u]) code = code_pl[(uint32_t)base[u] + (uint32_t)(c0 + lane)];
-                                irv_tally(code, hist, seen);
+                                irv_tally(code, hist, total);
                             }
                         }
                     }
                 }
             }
         }
-        for (int o2 = 32; o2 >= 1; o2 >>= 1) seen += __shfl_xor(seen, o2);
-        const int total = __builtin_amdgcn_readfirstlane(seen);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // first bin with the strictly largest count (d_dr_irv.cu:206-215): max over (count, -bin)
@@ -331,13 +344,9 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
             uint32_t k = (c << 16) | (uint32_t)(0xFFFF - b);
             if (c != 0 && k > key) key = k;
         }
-        for (int o2 = 32; o2 >= 1; o2 >>= 1) {
-            uint32_t other = (uint32_t)__shfl_xor((int)key, o2);
-            if (other > key) key = other;
-        }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        key = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+        key = wave_max_u32(key);
         int max_d = (int)own; // default: own disparity (d_dr_irv.cu:182)
         if (key != 0) max_d = (0xFFFF - (int)(key & 0xFFFF)) - zd;
         // apply (d_dr_irv.cu:32-41): the ratio uses the winning BIN INDEX, not its count (:36, SURVEY A-Q17 iv)
