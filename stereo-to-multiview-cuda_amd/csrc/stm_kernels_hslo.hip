@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void stm_k_hslo_h(HsloArgs a, int D, int zd, i
 #pragma unroll
         for (int j = 0; j < DPL; ++j) {
             r.c[j] = nt_load4(cp[j] + (size_t)g * gs[j]);
-            if (BWD) r.s[j] = nt_load4(ap[j] + (size_t)g * gs[j]);
+            if (BWD) r.s[j] = *(ap[j] + (size_t)g * gs[j]); // plain load: the end of the row is what left->right wrote last (4 % faster)
             r.c2[j] = *(const u32_unaligned *)(c2p[j] + 4 * g);
         }
         r.u = *(const uint32_t *)(up + 4 * g);
