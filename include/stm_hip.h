@@ -237,6 +237,12 @@ void *stm_stream_create(int num_rows, int num_cols_sbs, int num_cols, int num_ro
 long  stm_stream_submit(void *stream, const unsigned char *img_sbs);
 /* waits for the oldest uncollected frame and copies its results out (NULL = skip).  Returns its index or -1. */
 long  stm_stream_collect(void *stream, float *disp_l, float *disp_r, unsigned char *interlaced);
+/* zero-copy variants (at 1080p the two host copies of submit / collect take longer than the frame does on the GPU):
+ * the pinned input buffer of the slot the next submit will use (NULL while that slot is uncollected) -- write the frame
+ * into it and pass the same pointer (or NULL) to stm_stream_submit; and a collect that hands out pointers to the pinned
+ * result buffers, valid until the frame after the next one is submitted. */
+unsigned char *stm_stream_input_buffer(void *stream);
+long  stm_stream_collect_view(void *stream, const float **disp_l, const float **disp_r, const unsigned char **interlaced);
 void  stm_stream_destroy(void *stream);
 
 /* ----------------------------------------------------------------- BMP I/O */

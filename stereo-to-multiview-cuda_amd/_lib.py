@@ -67,6 +67,8 @@ PROTOS = {
     "stm_stream_create": ([i, i, i, i, i, i, i, f, i, i, f, f, f, f, i, i, i, f], C.c_void_p),
     "stm_stream_submit": ([C.c_void_p, u8p], C.c_long),
     "stm_stream_collect": ([C.c_void_p, f32p, f32p, u8p], C.c_long),
+    "stm_stream_input_buffer": ([C.c_void_p], C.c_void_p),
+    "stm_stream_collect_view": ([C.c_void_p, C.POINTER(f32p), C.POINTER(f32p), C.POINTER(u8p)], C.c_long),
     "stm_stream_destroy": ([C.c_void_p], None),
     "stm_bmp_read": ([C.c_char_p, C.POINTER(i), C.POINTER(i)], C.c_void_p),
     "stm_bmp_write": ([C.c_char_p, u8p, i, i], i),

@@ -28,6 +28,27 @@ class FrameStream:
         assert sbs.shape == (self.H, 2 * self.W, 3)
         return int(lib().stm_stream_submit(self._h, sbs.ctypes.data_as(u8p)))
 
+    def input_buffer(self):
+        """The pinned buffer the next submit() will use, as an (H, 2W, 3) uint8 view (None while that slot is uncollected):
+        write the frame into it and call submit_inplace() -- no host copy."""
+        p = lib().stm_stream_input_buffer(self._h)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(C.cast(p, u8p), shape=(self.H, 2 * self.W, 3))
+
+    def submit_inplace(self):
+        return int(lib().stm_stream_submit(self._h, None))
+
+    def collect_view(self):
+        """Like collect(), but returns views of the stream's pinned result buffers (valid until the frame after the next
+        one is submitted) instead of copies."""
+        pl, pr, po = f32p(), f32p(), u8p()
+        k = int(lib().stm_stream_collect_view(self._h, C.byref(pl), C.byref(pr), C.byref(po)))
+        if k < 0:
+            return None
+        return (k, np.ctypeslib.as_array(pl, shape=(self.H, self.W)), np.ctypeslib.as_array(pr, shape=(self.H, self.W)),
+                np.ctypeslib.as_array(po, shape=(self.Ho, self.Wo, 3)))
+
     def collect(self):
         dl = np.empty((self.H, self.W), np.float32)
         dr = np.empty((self.H, self.W), np.float32)

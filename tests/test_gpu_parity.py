@@ -533,6 +533,39 @@ def test_frame_stream_matches_per_frame_calls(gpu_ready, orc):
     assert np.array_equal(got[3][3], want["interlaced"]) and np.array_equal(got[3][1], want["disp_l"])
 
 
+def test_frame_stream_zero_copy(gpu_ready, orc):
+    """Frames written straight into the stream's pinned input buffer and results read through views of its pinned output
+    buffers (no host copies) equal the copying calls, frame for frame; a view stays valid until its slot is reused."""
+    from stm_amd import device_api as dev, host_api, synth, video
+    H, W, D, zd = 40, 72, 8, 4
+    p = dev.FrameParams(num_disp=D, zero_disp=zd, usd=9, lsd=4)
+    frames = [synth.sbs_frame(H, W, D, zd, seed=synth.SEED + 300 + k)[0] for k in range(6)]
+    fs = video.FrameStream(H, W, p)
+    got = []
+    pending = 0
+    for f in frames:
+        if pending == 2:
+            k, dl, dr, out = fs.collect_view()
+            got.append((k, dl.copy(), dr.copy(), out.copy()))
+            pending -= 1
+        buf = fs.input_buffer()
+        assert buf is not None and buf.shape == f.shape
+        buf[...] = f
+        assert fs.submit_inplace() >= 0
+        pending += 1
+    assert fs.input_buffer() is None  # both slots in flight
+    while pending:
+        k, dl, dr, out = fs.collect_view()
+        got.append((k, dl.copy(), dr.copy(), out.copy()))
+        pending -= 1
+    fs.close()
+    assert [g[0] for g in got] == list(range(6))
+    for k, f in enumerate(frames):
+        dl, dr, out = host_api.adcensus_stm(f, W, H, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd,
+                                            p.usd, p.lsd, p.thresh_s, p.thresh_h)
+        assert np.array_equal(got[k][1], dl) and np.array_equal(got[k][2], dr) and np.array_equal(got[k][3], out), k
+
+
 def test_frame_stream_graph_replay_survives_other_calls(gpu_ready, orc):
     """From its third frame on a stream slot replays a captured hipGraph whose kernel arguments point into the stream's
     private workspace.  Other library calls on the same thread -- here a much larger image, which regrows the shared

@@ -1,6 +1,7 @@
 """PCIe-inclusive rates of the host-buffer boundary at the bench workload (1920x1080, D=64, 8 views):
   (a) stm_adcensus_stm  - one blocking call per frame: upload, compute, download (the reference's adcensus_stm contract)
   (b) stm_stream_*      - the same frames through the double-buffered stream (upload k+1 || compute k || download k-1)
+  (c) the same stream through stm_stream_input_buffer / stm_stream_collect_view (no host-side copies)
 bench.py's `value` excludes the transfers; these numbers are what DESIGN.md section 5 quotes beside it.
 Usage (GPU box):  python tools/host_rate.py [frames [height width disp]]      (STM_STREAM_GRAPH=0: no hipGraph replay)
 """
@@ -54,6 +55,31 @@ while pending:
 dt_stream = (time.perf_counter() - t) / n
 fs.close()
 assert np.array_equal(last[3], ref[2]) and np.array_equal(last[1], ref[0])
+
+# (c) the same stream without the two host-side copies: frames written into the pinned input buffer, results read in place
+fs = video.FrameStream(H, W, p)
+for _ in range(2):
+    fs.input_buffer()[...] = sbs
+    fs.submit_inplace()
+fs.collect_view()
+fs.collect_view()
+src = fs.input_buffer()
+t = time.perf_counter()
+pending = 0
+for _ in range(n):
+    if pending == 2:
+        last = fs.collect_view()
+        pending -= 1
+    # a decoder would write the frame here; the synthetic frame is already in both pinned buffers
+    fs.submit_inplace()
+    pending += 1
+while pending:
+    last = fs.collect_view()
+    pending -= 1
+dt_zc = (time.perf_counter() - t) / n
+assert np.array_equal(last[3], ref[2]) and np.array_equal(last[1], ref[0])
+fs.close()
 print(json.dumps({"frames": n, "size": [H, W, D], "graph": os.environ.get("STM_STREAM_GRAPH", "1") != "0", "host_call_ms": round(dt_call * 1e3, 3), "host_call_fps": round(1 / dt_call, 1),
                   "stream_ms": round(dt_stream * 1e3, 3), "stream_fps": round(1 / dt_stream, 1),
+                  "stream_zero_copy_ms": round(dt_zc * 1e3, 3), "stream_zero_copy_fps": round(1 / dt_zc, 1),
                   "bytes_in": int(sbs.nbytes), "bytes_out": int(2 * H * W * 4 + H * W * 3)}))
