@@ -193,8 +193,8 @@ __global__ __launch_bounds__(IC_T) void stm_k_irv_compact(IrvArgs a, uint32_t HW
         if ((w >> (8 * j)) & 0xff) list[k++] = p + j;
 }
 
-constexpr int IV_WAVES = 4;     // waves per block
-constexpr int IV_PX_PER_BLOCK = 512; // grid per view = pixels / this (see launch_irv)
+constexpr int IV_WAVES = 2;     // waves per block
+constexpr int IV_PX_PER_BLOCK = 256; // grid per view = pixels / this (see launch_irv)
 constexpr int IV_U = 4;         // row pairs whose loads are in flight together
 
 // one LDS atomic per voting lane.  Merging equal bins with ballots first was measured slower in both forms tried
@@ -406,10 +406,11 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
                        nb);
     STM_CHECK_LAUNCH();
     const size_t smem = (size_t)nb * IV_WAVES * 4;
-    // Several times more blocks than the chip holds (1080p: 4050 blocks of 4 waves per view for 8192 wave slots): the waves walk
+    // Several times more waves than the chip holds (1080p: 8100 blocks of 2 waves per view for 8192 wave slots): the waves walk
     // the list with a fixed stride and outliers differ a lot in work, so freed slots must be refilled by the dispatcher --
-    // with exactly one resident grid (1024 blocks) the vote took 0.36 ms per frame instead of 0.30 (2048: 0.32, 16384: 0.32)
-    const int iv_blocks = (int)std::min<size_t>(std::max<size_t>((HW + IV_PX_PER_BLOCK - 1) / IV_PX_PER_BLOCK, 256), 16384);
+    // with exactly one resident grid (1024 blocks of 4 waves) the vote took 0.36 ms per frame, with 4096 such blocks 0.30,
+    // with 8100 blocks of 2 waves 0.29 (16384 blocks of 4: 0.32; single-wave blocks: no further gain)
+    const int iv_blocks = (int)std::min<size_t>(std::max<size_t>((HW + IV_PX_PER_BLOCK - 1) / IV_PX_PER_BLOCK, 256), 32768);
     for (int it = 0; it < rounds; ++it) {
         STM_LAUNCH(stm_k_irv_vote, dim3(iv_blocks, nviews), dim3(64 * IV_WAVES), smem, stream(), a, it, thresh_s, thresh_h, H,
                            W, nb, zd, usd, tiles_x, tiles_y);
