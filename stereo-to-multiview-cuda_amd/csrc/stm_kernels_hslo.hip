@@ -210,14 +210,15 @@ __device__ __forceinline__ float2 penalties(const float2 *ptab, uint32_t c2w, in
 // ------------------------------------------------------------------ horizontal passes
 // grid (cdiv(H, 4), views); block = 4 waves, one image row each.  BWD = false: left->right, acc = C_lr;
 // BWD = true: right->left, acc += C_rl.  PF = groups of four pixels loaded ahead of the walk.
+constexpr int HH_WPB = 1; // waves (image rows) per block in the horizontal passes: 2160 one-wave blocks spread over the 256 CUs as 8 or 9 each; four-row blocks gave some CUs 12 waves and others 8, and every pass ran at the pace of the fullest CU (0.49 + 0.73 -> 0.43 + 0.64 ms)
 template <int DPL, bool BWD, int PF>
-__global__ __launch_bounds__(256) void stm_k_hslo_h(HsloArgs a, int D, int zd, int H, int W, int G, int WU, int WP, int PAD, int dbg)
+__global__ __launch_bounds__(64 * HH_WPB) void stm_k_hslo_h(HsloArgs a, int D, int zd, int H, int W, int G, int WU, int WP, int PAD, int dbg)
 {
     __shared__ float2 ptab[9];
     if (threadIdx.x < 9) ptab[threadIdx.x] = make_float2(a.p1[threadIdx.x], a.p2[threadIdx.x]);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int y = blockIdx.x * 4 + wave, view = blockIdx.y;
+    const int y = blockIdx.x * HH_WPB + wave, view = blockIdx.y;
     if (y >= H) return; // whole wave; no block barrier below
     const int osign = a.osign[view];
     const f4 *cp[DPL];
@@ -452,12 +453,12 @@ void hslo_passes(const HsloArgs &a, int nviews, int D, int zd, int H, int W, int
     const int dbg = (agg_variant() / 100000) % 10; // timing experiments only (stm_hip.h): 1 = no recurrence, 2 = no stores
     {
         ProfScope p("hslo_lr");
-        STM_LAUNCH((stm_k_hslo_h<DPL, false, PF>), dim3(cdiv(H, 4), nviews), dim3(256), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD, dbg);
+        STM_LAUNCH((stm_k_hslo_h<DPL, false, PF>), dim3(cdiv(H, HH_WPB), nviews), dim3(64 * HH_WPB), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD, dbg);
         STM_CHECK_LAUNCH();
     }
     {
         ProfScope p("hslo_rl");
-        STM_LAUNCH((stm_k_hslo_h<DPL, true, PF>), dim3(cdiv(H, 4), nviews), dim3(256), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD, dbg);
+        STM_LAUNCH((stm_k_hslo_h<DPL, true, PF>), dim3(cdiv(H, HH_WPB), nviews), dim3(64 * HH_WPB), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD, dbg);
         STM_CHECK_LAUNCH();
     }
     {
