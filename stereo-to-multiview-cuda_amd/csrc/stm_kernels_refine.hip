@@ -225,9 +225,10 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // Iteration `it` (0-based): vote (dr_irv_pre_kernel, d_dr_irv.cu:134-220) and apply (dr_irv_kernel_3, :17-43) for
 // every live pixel of the outlier list.
 // One wave per outlier, one region row per wave step (lanes = pixels of the row segment, coalesced), IV_U rows
-// in flight together.  The kernel is instruction-issue bound (8 waves per SIMD hide all latency), so everything
-// that is uniform over the wave is kept in SGPRs: row arms are fetched once into lanes and broadcast with
-// v_readlane, row offsets are 32-bit scalar arithmetic.
+// in flight together.  Everything that is uniform over the wave is kept in SGPRs: row arms are fetched once into lanes
+// (already clamped into the image) and broadcast with v_readlane, row offsets are 32-bit scalar arithmetic.  Its waves
+// spend half their time in s_waitcnt, so LDS round trips are avoided (DPP reductions), and the work per outlier is
+// uneven, so the grid is several resident sets of small blocks (launch_irv).
 // Apply in the same kernel: the reference votes for ALL outliers on one state and only then updates it.  Here the
 // votes read code plane `it & 1`, which nothing writes during this launch; an accepted pixel is written to the
 // disparity / outlier maps (no vote reads them) and to the OTHER code plane, and its list entry is tagged
