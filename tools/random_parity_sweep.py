@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 bad = 0
 for case in range(n):
-    H = int(rng.randint(3, 90)); W = int(rng.randint(3, 400)); D = int(rng.choice([3, 8, 16, 17, 31, 64, 65, 100]))
+    H = int(rng.randint(3, 90)); W = int(rng.randint(3, int(os.environ.get("WMAX", "400")))); D = int(rng.choice([3, 8, 16, 17, 31, 64, 65, 100]))
     zd = int(rng.randint(0, D)); usd = int(rng.choice([1, 5, 17, 34, 40, 63])); lsd = int(rng.randint(1, usd + 1))
     hslo = bool(rng.randint(0, 2))
     sbs, _ = synth.sbs_frame(H, W, D, zd, seed=1000 + case)
