@@ -703,8 +703,7 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
         const u8 *u[2] = {al.up, ar.up}, *d[2] = {al.down, ar.down}, *l[2] = {al.left, ar.left}, *r[2] = {al.right, ar.right};
         launch_irv(2, dv, ov, u, d, l, r, thresh_s, thresh_h, H, W, D, zero_disp, usd, 5, true);
     }
-    launch_bilateral(wl, d_disp_l, gauss2d_table(7, 10.0f), gauss1d_table(D, 5.0f), 7, H, W, D); // :150  (7, 5, 10)
-    launch_bilateral(wr, d_disp_r, gauss2d_table(7, 10.0f), gauss1d_table(D, 5.0f), 7, H, W, D); // :151
+    launch_bilateral2(wl, d_disp_l, wr, d_disp_r, gauss2d_table(7, 10.0f), gauss1d_table(D, 5.0f), 7, H, W, D); // :150-151  (7, 5, 10)
 }
 
 // hit maps -> bleed -> masks -> N-2 views -> interlace (d_io.cu:160-205)

@@ -143,6 +143,8 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
                 int H, int W, int D, int zd, int usd, int iterations, bool device_flavour);
 void launch_bilateral(const float *in, float *out, const float *spatial, const float *color,
                       int radius, int H, int W, int D);
+void launch_bilateral2(const float *in_a, float *out_a, const float *in_b, float *out_b, const float *spatial, const float *color,
+                       int radius, int H, int W, int D);
 void launch_gaussian_max(const float *in, float *out, const float *spatial, int radius, float sigma, int H, int W,
                          bool invert_input);
 // DIBR + mux (stm_kernels_dibr.hip)

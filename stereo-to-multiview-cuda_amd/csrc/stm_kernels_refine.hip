@@ -480,10 +480,13 @@ __global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_gaussian_max_r(const float
 }
 
 template <int R>
-__global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_bilateral_r(const float *__restrict__ in, float *__restrict__ out,
+__global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_bilateral_r(const float *__restrict__ in0, float *__restrict__ out0,
+                                                                 const float *__restrict__ in1, float *__restrict__ out1,
                                                                  const float *__restrict__ spatial,
                                                                  const float *__restrict__ color, int H, int W, int ncolor)
 {
+    const float *__restrict__ in = blockIdx.z ? in1 : in0; // both views of a frame share the launch
+    float *__restrict__ out = blockIdx.z ? out1 : out0;
     constexpr int KW = 2 * R + 1, NF = (KW + 3 + 3) / 4 * 4;
     constexpr int TW = (SF_TX * 4 + 2 * R + 3) / 4 * 4 + 4, TH = SF_TY + 2 * R;
     __shared__ float4 tile4[TH * TW / 4];
@@ -593,13 +596,28 @@ __global__ __launch_bounds__(ST_TX *ST_TY) void stm_k_bilateral(const float *__r
     out[(size_t)gy * W + gx] = res / norm;
 }
 
+// the frame pipeline's two maps (left, right) in one launch of the radius-7 kernel
+void launch_bilateral2(const float *in_a, float *out_a, const float *in_b, float *out_b, const float *spatial, const float *color,
+                       int radius, int H, int W, int D)
+{
+    if (radius != 7) {
+        launch_bilateral(in_a, out_a, spatial, color, radius, H, W, D);
+        launch_bilateral(in_b, out_b, spatial, color, radius, H, W, D);
+        return;
+    }
+    ProfScope p("bilateral");
+    STM_LAUNCH(stm_k_bilateral_r<7>, dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY), 2), dim3(SF_TX, SF_TY), (size_t)D * 4, stream(), in_a, out_a,
+               in_b, out_b, spatial, color, H, W, D);
+    STM_CHECK_LAUNCH();
+}
+
 void launch_bilateral(const float *in, float *out, const float *spatial, const float *color, int radius, int H, int W,
                       int D)
 {
     if (radius == 7) {
         ProfScope p("bilateral");
         STM_LAUNCH(stm_k_bilateral_r<7>, dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY)), dim3(SF_TX, SF_TY), (size_t)D * 4, stream(),
-                           in, out, spatial, color, H, W, D);
+                           in, out, in, out, spatial, color, H, W, D);
         STM_CHECK_LAUNCH();
         return;
     }
