@@ -638,7 +638,7 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
     const size_t HW = (size_t)H * W;
     const int NQ = (D + 3) / 4;
     const size_t V = HW * NQ * 4; // volumes are kept quad-interleaved (float4 [NQ][H][W]) inside the frame
-    const bool matrix_pipe = (agg_variant() / 10000) % 10 != 1 && aggm_supports(usd); // default aggregation path: stm_kernels_aggm.hip
+    const bool matrix_pipe = (agg_variant() / 10000) % 10 != 1 && aggm_supports(usd, H, W); // default aggregation path: stm_kernels_aggm.hip
     float *cost = matrix_pipe ? nullptr : Workspace::get<float>(2 * V), *scratch = matrix_pipe ? nullptr : Workspace::get<float>(V);
     uint32_t *pk_l = pre ? pre[0] : Workspace::get<uint32_t>(HW), *pk_r = pre ? pre[1] : Workspace::get<uint32_t>(HW);
     Vol cl = vol_quads(cost, HW), cr = vol_quads(cost ? cost + V : nullptr, HW), sc = vol_quads(scratch, HW);

@@ -177,7 +177,7 @@ struct PQViews { // both views of a frame; a / b = the two PQ volumes of a view
     float *disp[2];
 };
 size_t pq_volume_floats(int D, int H, int W);
-bool aggm_supports(int usd);
+bool aggm_supports(int usd, int H, int W);
 void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, const float *lut, float *const *vol_a, float *const *vol_b,
                        const u8 *const *armU, const u8 *const *armD, const u8 *const *armL, const u8 *const *armR, float *const *disp,
                        int D, int zd, int H, int W, int usd, bool keep_volume = false);

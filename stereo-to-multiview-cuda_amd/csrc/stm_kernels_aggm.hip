@@ -526,10 +526,264 @@ __global__ __launch_bounds__(128 * NTP) void stm_k_pq_v12(PQViews v, int H, int 
     }
 }
 
+// ------------------------------------------------------------------ both vertical passes, fused, table-driven (round 3)
+// Same decomposition as stm_k_pq_v12 (block = 4 columns x 16 hypotheses, NTP first-pass waves + NTP second-pass waves, two
+// barriers per step of 16 NTP rows), with everything that is not the window sweep taken out of the vector ALU -- on gfx950
+// the f32 MFMAs run on the SIMD's vector ALU, so every other VALU instruction is time the sweep does not get (round-2
+// counters: 8.1 VALU instructions per MFMA in stm_k_pq_v12, profiles/r03_pmc_sq_aggm.txt):
+//  * the window masks of a tile (16 rows x 4 columns) are the same for the 4 chunk blocks of a strip and for both passes, so
+//    stm_k_vwin_table ballots them ONCE per frame into 64-bit lane masks: the sweep fetches four of them with one
+//    s_load_dwordx8 and forms the A operand with ONE v_cndmask_b32 per MFMA (was add + compare + select per column); the
+//    same record carries the sweep's first row and length (were four DPP min/max reductions per tile);
+//  * rings hold QUADS of rows, float4 [quad slot][column b][hypothesis n] = rows 4q..4q+3: the B operands of four window rows
+//    are one ds_read_b128 (were four ds_read_b32), a first-pass tile leaves as four ds_write_b128 straight from its
+//    accumulator registers (were sixteen ds_write_b32), sweeps start on a quad boundary as before;
+//  * global loads and stores are buffer instructions whose row offset is one v_add of a scalar: rows past the image are
+//    dropped by the buffer's range check, no 64-bit address arithmetic, no clamps.
+// Table record of tile (view, u = y / 16, g), `rec` dwords: [0] K0 (first row of the sweep, multiple of 4), [1] n_it
+// (sweep length in quads), [8 + 8 it ..] the four 64-bit masks of quad it: bit 16 b + i = row 16 u + i of column 4 g + b has
+// row K0 + 4 it + j in its window [y - armU, y + armD)  (d_ca_cross_sum.cu:172-173,189-194).
+__global__ __launch_bounds__(256) void stm_k_vwin_table(PQViews v, uint32_t *__restrict__ tab, int rec, int H, int W, int G, int nT)
+{
+    const int l = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6), u = blockIdx.y, view = blockIdx.z;
+    if (g >= G) return; // uniform per wave
+    const u8 *__restrict__ armU = view ? v.armU[1] : v.armU[0], *__restrict__ armD = view ? v.armD[1] : v.armD[0];
+    const int b = l >> 4, i = l & 15, y = u * 16 + i, x = 4 * g + b;
+    int s0 = 0, nn = 0;
+    if (y < H && x < W) {
+        const int aU = armU[(size_t)y * W + x], aD = armD[(size_t)y * W + x];
+        s0 = y - aU;
+        nn = aU + aD;
+    }
+    const int lo = wave_min_i(nn ? s0 : 0x7fffffff);
+    const int hi = wave_max_i(nn ? s0 + nn : -0x7fffffff);
+    const int K0 = hi > lo ? (lo & ~3) : 0, n_it = hi > lo ? (hi - K0 + 3) >> 2 : 0;
+    uint32_t *dst = tab + ((size_t)(view * nT + u) * G + g) * rec;
+    if (l < 8) dst[l] = l == 0 ? (uint32_t)K0 : l == 1 ? (uint32_t)n_it : 0u;
+    unsigned long long *mk = (unsigned long long *)(dst + 8);
+    const int steps = 4 * n_it;
+    for (int base = 0; base < steps; base += 64) {
+        unsigned long long mine = 0;
+        const int cnt = min(64, steps - base);
+        for (int j = 0; j < cnt; ++j) {
+            const unsigned long long m = __ballot((unsigned)(K0 + base + j - s0) < (unsigned)nn);
+            if (l == j) mine = m;
+        }
+        if (l < cnt) mk[base + l] = mine;
+    }
+}
+
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+#define STM_MASKF(m) (__builtin_amdgcn_inverse_ballot_w64(m) ? 1.0f : 0.0f)
+// 16-byte buffer load, streaming (nt).  The builtin's vector is converted as a whole: indexing its elements directly
+// returned element 0 for every index with this compiler (ROCm 7.2).
+#define STM_BLOAD(rsrc, voff) __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 2))
+
+// Sweep of one tile: quads K0 / 4 .. K0 / 4 + n_it - 1 of a ring of RQ quad slots.  Two register sets (A, B) alternate: the
+// loads of a quad (LDS float4, four masks) are issued while the MFMAs of the quad before run.  LDS and scalar loads share one
+// counter and scalar loads return out of order, so a set is waited for (STM_V12_ARRIVED) BEFORE the other set's loads are
+// issued; the sched_barriers keep the compiler from re-rolling that order.
+// the window table is read through the CONSTANT address space: uniform loads from it are always scalar loads (it is
+// written by stm_k_vwin_table, an earlier launch of the same stream, and only read here)
+typedef __attribute__((address_space(4))) const uint32_t ctab32;
+typedef __attribute__((address_space(4))) const unsigned long long ctab64;
+struct V12Quad { f4 c; unsigned long long m0, m1, m2, m3; };
+struct V12Sweep { // a tile's sweep whose first quad is already on its way (issued before the step's barrier)
+    const f4 *p;
+    ctab64 *mk;
+    int qs, n_it;
+    V12Quad A;
+};
+#define STM_V12_LOAD(S, Q, RQ)                                                      \
+    {                                                                               \
+        Q.c = *S.p;                                                                 \
+        Q.m0 = S.mk[0]; Q.m1 = S.mk[1]; Q.m2 = S.mk[2]; Q.m3 = S.mk[3];             \
+        S.p += 64; S.mk += 4;                                                       \
+        if (++S.qs == RQ) { S.qs = 0; S.p -= RQ * 64; } /* uniform */               \
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);           \
+    }
+#define STM_V12_ARRIVED(Q) __builtin_amdgcn_sched_barrier(0); asm volatile("" : : "v"(Q.c), "s"(Q.m0), "s"(Q.m1), "s"(Q.m2), "s"(Q.m3) : "memory");
+#define STM_V12_MFMA(Q)                                                                                            \
+    {                                                                                                              \
+        const float a0 = STM_MASKF(Q.m0), a1 = STM_MASKF(Q.m1), a2 = STM_MASKF(Q.m2), a3 = STM_MASKF(Q.m3);        \
+        acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a0, Q.c.x, acc, 0, 0, 0);                                       \
+        acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a1, Q.c.y, acc, 0, 0, 0);                                       \
+        acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a2, Q.c.z, acc, 0, 0, 0);                                       \
+        acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a3, Q.c.w, acc, 0, 0, 0);                                       \
+    }
+// hdr = {K0, n_it} of the tile's record `r`; slot0 = ring slot of the tile's first own quad (row 16 u); u4 = 4 u
+__device__ __forceinline__ void v12t_begin(V12Sweep &S, const f4 *ring_l, int RQ, int slot0, int u4, ctab32 *r, int K0, int n_it)
+{
+    int qs = slot0 + ((K0 >> 2) - u4); // (K0 >> 2) - 4 u in [-UQ / 4, 3]
+    if (qs < 0) qs += RQ;
+    if (qs >= RQ) qs -= RQ;
+    S.qs = qs;
+    S.n_it = n_it;
+    S.p = ring_l + qs * 64;
+    S.mk = (ctab64 *)(r + 8);
+    STM_V12_LOAD(S, S.A, RQ) // n_it == 0: any slot, any masks, unused
+}
+__device__ __forceinline__ f16v v12t_run(V12Sweep &S, int RQ)
+{
+    f16v acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    V12Quad B;
+    int it = 0;
+    const int n_it = S.n_it;
+    for (; it + 2 <= n_it; it += 2) {
+        STM_V12_ARRIVED(S.A)
+        STM_V12_LOAD(S, B, RQ)
+        STM_V12_MFMA(S.A)
+        STM_V12_ARRIVED(B)
+        STM_V12_LOAD(S, S.A, RQ) // on the last trip: one quad past the sweep (any ring slot; the record is a quad longer than the longest sweep)
+        STM_V12_MFMA(B)
+    }
+    if (it < n_it) STM_V12_MFMA(S.A)
+    return acc;
+}
+
+template <int NTP>
+__global__ __launch_bounds__(128 * NTP) void stm_k_pq_v12t(PQViews v, const uint32_t *__restrict__ wtab, int rec, int H, int W, int G,
+                                                           int NC, int UQ, int RQ1, int RQ2, int LAG)
+{
+    constexpr int TS = 16 * NTP, TQ = 4 * NTP, NTH = 128 * NTP; // rows, quads per step; threads
+    extern __shared__ f4 lds4[];
+    f4 *ring1 = lds4, *ring2 = lds4 + RQ1 * 64; // a quad slot = float4 [4 columns][16 hypotheses] = rows 4q..4q+3 (1 KB)
+    const int view = blockIdx.z, c = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int l = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool second = wid >= NTP;
+    const int ti = wid - (second ? NTP : 0);
+    const int nT = (H + 15) >> 4, nS = (nT + NTP - 1) / NTP;
+    const int rsb = G * 256; // bytes between consecutive rows of the strip
+    const size_t strip = ((size_t)c * H * G + g) * 16; // float4 index of (chunk c, row 0, group g, hypothesis 0)
+    const uint32_t range = (uint32_t)(H - 1) * (uint32_t)rsb + 256u;
+    for (int i = tid; i < (RQ1 + RQ2) * 64; i += NTH) lds4[i] = f4{0.f, 0.f, 0.f, 0.f}; // masked steps multiply ring contents by 0
+    ctab32 *trow = (ctab32 *)(uintptr_t)(wtab + ((size_t)view * nT * G + g) * rec); // + u * G * rec: record of tile u
+    const size_t tstep = (size_t)G * rec;
+    // records of the tiles this wave sweeps: headers are fetched one step ahead (tiles past the image: the last tile's record, unused)
+#define STM_V12_HDR(U, K0_, NIT_)                                                \
+    {                                                                            \
+        ctab32 *r_ = trow + (size_t)min(max(U, 0), nT - 1) * tstep;                       \
+        K0_ = (int)r_[0];                                                        \
+        NIT_ = (int)r_[1];                                                       \
+    }
+    __syncthreads();
+    if (!second) {
+        // ---------------------------------------------------------------- first pass: ring 1 -> ring 2, all global loads
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)((const f4 *)(view ? v.b[1] : v.b[0]) + strip), 0, range, 0x00020000);
+        const int qq = tid >> 4, n = tid & 15; // loader role: quad qq of a step's TQ quads, hypothesis n
+        int vo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vo[k] = (4 * qq + k) * rsb + n * 16;
+        // rows [0, TS + UQ) before step 0 (UQ = usd rounded up to a quad: the windows of step t end before row TS (t + 1) + usd)
+        const int nq0 = (TS + UQ) >> 2;
+        for (int q0 = 0; q0 < nq0; q0 += TQ) {
+            f4 tmp[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tmp[k] = STM_BLOAD(rin, vo[k] + q0 * 4 * rsb);
+            if (q0 + qq < nq0) {
+                f4 *q = ring1 + (q0 + qq) * 64 + n; // nq0 <= RQ1: no wrap yet
+#pragma unroll
+                for (int b = 0; b < 4; ++b) q[16 * b] = f4{tmp[0][b], tmp[1][b], tmp[2][b], tmp[3][b]};
+            }
+        }
+        int ld_q = nq0;                       // first quad not yet in the ring (uniform)
+        int ld_slot = nq0 == RQ1 ? 0 : nq0;   // its ring slot
+        // input rows travel two steps ahead of their use (HBM latency under load exceeds one step): two register sets take turns,
+        // X = the rows the NEXT step adds (written to the ring at the end of this step), Y = those of the step after
+        f4 X[4], Y[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X[k] = STM_BLOAD(rin, vo[k] + ld_q * 4 * rsb);
+        int u = ti;
+        int s1 = 4 * ti, s2 = 4 * ti; // ring slots of the tile's first quad (both rings hold more than one step)
+        int K0, n_it, K0n, n_itn;
+        STM_V12_HDR(u, K0, n_it)
+        V12Sweep S;
+        const bool early = UQ > 16 * (NTP - 1);
+        __syncthreads(); // initial rows visible
+        if (early) v12t_begin(S, ring1 + l, RQ1, s1, 4 * u, trow + (size_t)min(u, nT - 1) * tstep, K0, n_it);
+#define STM_V12_STEP1(PRE, FAR)                                                                                              \
+    {                                                                                                                        \
+        __syncthreads(); /* ring 1 holds the rows of this step */                                                            \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) FAR[k] = STM_BLOAD(rin, vo[k] + (ld_q + TQ) * 4 * rsb);                \
+        if (!early) v12t_begin(S, ring1 + l, RQ1, s1, 4 * u, trow + (size_t)min(u, nT - 1) * tstep, K0, n_it);               \
+        STM_V12_HDR(u + NTP, K0n, n_itn)                                                                                     \
+        if (u < nT) {                                                                                                        \
+            const f16v acc = v12t_run(S, RQ1);                                                                               \
+            /* registers 4b..4b+3 of lane 16q + n = out[rows 16u + 4q .. +3][column b][hypothesis n]: one float4 per column */ \
+            int so = s2 + (l >> 4);                                                                                          \
+            if (so >= RQ2) so -= RQ2;                                                                                        \
+            f4 *q = ring2 + so * 64 + (l & 15);                                                                              \
+            _Pragma("unroll") for (int b = 0; b < 4; ++b) q[16 * b] = f4{acc[4 * b], acc[4 * b + 1], acc[4 * b + 2], acc[4 * b + 3]}; \
+        }                                                                                                                    \
+        s1 += TQ;                                                                                                            \
+        if (s1 >= RQ1) s1 -= RQ1;                                                                                            \
+        s2 += TQ;                                                                                                            \
+        if (s2 >= RQ2) s2 -= RQ2;                                                                                            \
+        __syncthreads(); /* everyone is done reading ring 1: the oldest TQ quads can be replaced */                           \
+        {                                                                                                                    \
+            int sw = ld_slot + qq;                                                                                           \
+            if (sw >= RQ1) sw -= RQ1;                                                                                        \
+            f4 *q = ring1 + sw * 64 + n; /* rows past the image: the buffer returned zeros */                                \
+            _Pragma("unroll") for (int b = 0; b < 4; ++b) q[16 * b] = f4{PRE[0][b], PRE[1][b], PRE[2][b], PRE[3][b]};        \
+        }                                                                                                                    \
+        ld_q += TQ;                                                                                                          \
+        ld_slot += TQ;                                                                                                       \
+        if (ld_slot >= RQ1) ld_slot -= RQ1;                                                                                  \
+        u += NTP;                                                                                                            \
+        K0 = K0n;                                                                                                            \
+        n_it = n_itn;                                                                                                        \
+        /* the next tile's first quad (rows < 16 u + 16 (NTP - 1)) was written at least a step ago when the rows being written */ \
+        /* now start later (16 (NTP - 1) < UQ): fetch it in front of the barrier */                                          \
+        if (early) v12t_begin(S, ring1 + l, RQ1, s1, 4 * u, trow + (size_t)min(u, nT - 1) * tstep, K0, n_it);                \
+    }
+        const int nst = nS + LAG;
+        for (int t = 0; t < nst; t += 2) {
+            STM_V12_STEP1(X, Y)
+            if (t + 1 < nst) STM_V12_STEP1(Y, X)
+        }
+#undef STM_V12_STEP1
+    } else {
+        // ---------------------------------------------------------------- second pass: ring 2 -> HBM, all stores, LAG steps behind
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)((f4 *)(view ? v.a[1] : v.a[0]) + strip), 0, range, 0x00020000);
+        int vo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vo[i] = (4 * (l >> 4) + i) * rsb + (l & 15) * 16;
+        int u = -LAG * NTP + ti;
+        int s2 = 4 * ti; // ring slot of the first quad of tile max(u, 0)
+        int K0, n_it, K0n, n_itn;
+        STM_V12_HDR(u, K0, n_it)
+        V12Sweep S;
+        __syncthreads();
+        v12t_begin(S, ring2 + l, RQ2, s2, 4 * max(u, 0), trow + (size_t)min(max(u, 0), nT - 1) * tstep, K0, n_it);
+        const int nst = nS + LAG;
+        for (int t = 0; t < nst; ++t) {
+            __syncthreads(); // ring 2 holds the first-pass rows of the steps before
+            STM_V12_HDR(u + NTP, K0n, n_itn)
+            if (u >= 0 && u < nT) {
+                const f16v acc = v12t_run(S, RQ2);
+                const int ro = 16 * u * rsb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f4 o = {acc[i], acc[4 + i], acc[8 + i], acc[12 + i]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, o), rout, vo[i] + ro, 0, 2); // rows >= H: out of range, dropped
+                }
+                s2 += TQ;
+                if (s2 >= RQ2) s2 -= RQ2;
+            }
+            __syncthreads();
+            u += NTP;
+            v12t_begin(S, ring2 + l, RQ2, s2, 4 * max(u, 0), trow + (size_t)min(max(u, 0), nT - 1) * tstep, K0n, n_itn);
+        }
+    }
+#undef STM_V12_HDR
+}
+
 // ------------------------------------------------------------------ launchers
 size_t pq_volume_floats(int D, int H, int W) { return (size_t)((D + 15) / 16) * H * ((W + 3) / 4) * 64; }
 
-// LDS of the fused vertical kernel: two rings of (48 + 2 usd) and (48 (LAG + 1) + usd) rows of 256 B
+// LDS of the round-2 fused vertical kernel: two rings of (48 + 2 usd) and (48 (LAG + 1) + usd) rows of 256 B
 static size_t v12_smem(int usd, int ntp)
 {
     const int TS = 16 * ntp;
@@ -538,8 +792,19 @@ static size_t v12_smem(int usd, int ntp)
     const int R2 = (TS * (LAG + 1) + usd + 3) & ~3;
     return (size_t)(R1 + R2) * 256 + (size_t)(LAG + 1) * ntp * 64 * 8; // + the ring of windows the first pass hands to the second
 }
-// arms longer than this do not fit the CU's 160 KB: the caller falls back to the vector-ALU kernels (stm_kernels_agg.hip)
-bool aggm_supports(int usd) { return usd >= 1 && v12_smem(usd > 255 ? 255 : usd, 3) <= 160 * 1024; }
+// LDS of the table-driven fused vertical kernel: rings of (48 + 2 UQ) and (48 (LAG + 1) + UQ) rows of 256 B, UQ = usd rounded up to 4
+static size_t v12t_smem(int usd)
+{
+    const int TS = 48, UQ = (usd + 3) & ~3, LAG = (UQ + TS - 1) / TS + 1;
+    return (size_t)(TS + 2 * UQ + TS * (LAG + 1) + UQ) * 256;
+}
+// arms longer than this do not fit the CU's 160 KB, and the kernels address a strip of the volume with 32-bit byte offsets:
+// the caller falls back to the vector-ALU kernels (stm_kernels_agg.hip)
+bool aggm_supports(int usd, int H, int W)
+{
+    if (usd > 255) usd = 255;
+    return usd >= 1 && v12t_smem(usd) <= 160 * 1024 && (unsigned long long)H * ((W + 3) / 4) * 256ull < (1ull << 31);
+}
 
 // cost -> H -> V, V -> H + WTA for both views of a frame.  vol_a / vol_b: two PQ volumes per view (pq_volume_floats each).
 // keep_volume: the last pass writes the aggregated costs to vol_b instead of doing WTA (the HSLO stage follows; disp unused).
@@ -590,6 +855,25 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
         }
         STM_CHECK_LAUNCH();
     }
+    if ((agg_variant() / 100) % 10 != 1) {
+        // table-driven fused vertical kernel (round 3); the window table is built once per frame for both views
+        constexpr int NTP = 3, TS = 16 * NTP;
+        const int UQ = (usd + 3) & ~3, nT = (H + 15) / 16;
+        const int rec = 8 + 8 * ((2 * usd + 21) / 4 + 2); // header + the longest sweep + one quad of read-ahead
+        const int LAG = (UQ + TS - 1) / TS + 1;
+        const int RQ1 = (TS + 2 * UQ) / 4, RQ2 = (TS * (LAG + 1) + UQ) / 4;
+        uint32_t *tab = Workspace::get<uint32_t>((size_t)2 * nT * G * rec);
+        {
+            ProfScope p("pq_vtab");
+            STM_LAUNCH(stm_k_vwin_table, dim3(cdiv(G, 4), nT, 2), dim3(256), 0, stream(), v, tab, rec, H, W, G, nT);
+            STM_CHECK_LAUNCH();
+        }
+        ProfScope p("pq_v12");
+        const size_t smem = (size_t)(RQ1 + RQ2) * 1024;
+        allow_lds_m((const void *)stm_k_pq_v12t<NTP>, smem);
+        STM_LAUNCH(stm_k_pq_v12t<NTP>, dim3(G, NC, 2), dim3(128 * NTP), smem, stream(), v, tab, rec, H, W, G, NC, UQ, RQ1, RQ2, LAG);
+        STM_CHECK_LAUNCH();
+    } else
     {
         ProfScope p("pq_v12");
         const int ntp = (agg_variant() / 10000000) % 10 ? (agg_variant() / 10000000) % 10 : 3;
