@@ -66,10 +66,12 @@ void        stm_prof_reset(void);
  * summed duration in ms; synchronises the recorded events. */
 int         stm_prof_read(const char *kernel, float *total_ms);
 /* aggregation variant of the frame pipeline (0 = default: matrix-pipe kernels, stm_kernels_aggm.hip); decimal digits, used by
- * the benchmark and the tools to A/B variants in one process: 10000 = vector-ALU aggregation kernels (stm_kernels_agg.hip; the
- * low digits then select their tunables), 1000000 = separate initial-cost kernel instead of computing the costs inside the
- * first pass, N0000000 (N = 1..4) = N row tiles per pass and step in the fused vertical kernel, N00000 = timing experiments
- * (results are NOT valid: parts of the kernels are skipped; in the HSLO passes 1 = no recurrence, 2 = no volume stores) */
+ * the benchmark and the tools to A/B result-preserving variants in one process: 10000 = vector-ALU aggregation kernels
+ * (stm_kernels_agg.hip; the low digits then select their tunables), 1000000 = separate initial-cost kernel instead of
+ * computing the costs inside the first pass, 1000 = 128-pixel segments in the cost-computing pass, 10 = the last horizontal
+ * pass as one block per segment instead of the streaming row walk.  Every accepted variant produces identical results.  The
+ * digit N00000 (timing experiments that skip parts of kernels) is ignored here: it exists only in libstm_hip_timing.so,
+ * a separate build of the same sources with -DSTM_TIMING (csrc/Makefile, `make timing`). */
 void        stm_set_agg_variant(int v);
 
 /* ------------------------------------------------------- cost init (a1-a7) */

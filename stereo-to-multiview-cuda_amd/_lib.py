@@ -7,6 +7,10 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libstm_hip.so")
+# STM_LIB=timing: the tools/*_time.py experiments load the -DSTM_TIMING build of the same sources (kernels with parts
+# switched off; results NOT valid).  Nothing else ever loads it.
+if os.environ.get("STM_LIB") == "timing":
+    LIB_PATH = os.path.join(HERE, "libstm_hip_timing.so")
 
 u8p = C.POINTER(C.c_uint8)
 f32p = C.POINTER(C.c_float)

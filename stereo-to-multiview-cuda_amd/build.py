@@ -10,7 +10,7 @@ def build(force=False, jobs=8):
     csrc = os.path.join(HERE, "csrc")
     if force:
         subprocess.check_call(["make", "-s", "-C", csrc, "clean"])
-    subprocess.check_call(["make", "-s", "-j%d" % jobs, "-C", csrc, "all"])
+    subprocess.check_call(["make", "-s", "-j%d" % jobs, "-C", csrc, "all", "timing"])
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("hipcc build did not produce %s" % LIB_PATH)
     return LIB_PATH

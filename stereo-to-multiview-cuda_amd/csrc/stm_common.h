@@ -54,6 +54,16 @@ struct ProfScope {
 };
 
 int agg_variant();
+// Timing experiments (skip loads / sweeps / stores; results NOT valid) exist only in the separate libstm_hip_timing.so
+// (make timing, -DSTM_TIMING): in the product library every STM_DBG test is the constant false and stm_set_agg_variant
+// accepts result-preserving variants only.
+#ifdef STM_TIMING
+#define STM_DBG(dbg, bit) (((dbg) & (bit)) != 0)
+static inline int timing_knobs() { return (agg_variant() / 100000) % 10; }
+#else
+#define STM_DBG(dbg, bit) false
+static inline int timing_knobs() { return 0; }
+#endif
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

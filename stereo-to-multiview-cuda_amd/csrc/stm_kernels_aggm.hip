@@ -36,6 +36,12 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define STM_MFMA16(m, b, acc, abid) __builtin_amdgcn_mfma_f32_16x16x1f32(m, b, acc, 2, abid, 0)
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+#define STM_MASKF(m) (__builtin_amdgcn_inverse_ballot_w64(m) ? 1.0f : 0.0f)
+// 16-byte buffer load, streaming (nt).  The builtin's vector is converted as a whole: indexing its elements directly
+// returned element 0 for every index with this compiler (ROCm 7.2).
+#define STM_BLOAD(rsrc, voff) __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 2))
+
 
 // rotate within each row of 16 lanes (DPP row_ror:n)
 template <int N> __device__ __forceinline__ float row_ror_f(float v)
@@ -240,21 +246,18 @@ __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, 
                     tile[cl * NG * 16 + rr] = val;
                 }
             }
-        } else
-        for (int r0 = 0; r0 < NG * 16; r0 += 2 * NT) {
-            f4 tmp[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int cl = k & 3, r = r0 + (k >> 2) * NT + tid;
-                const f4 *__restrict__ rowp = in + ((size_t)min(c0 + cl, NC - 1) * H + y) * G * 16; // uniform: scalar base
-                const int g = min(max(gbase + (r >> 4), 0), G - 1);
-                tmp[k] = (dbg & 4) ? zero4 : rowp[g * 16 + (r & 15)];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int cl = k & 3, r = r0 + (k >> 2) * NT + tid;
-                const int g = gbase + (r >> 4);
-                if (r < NG * 16) tile[cl * NG * 16 + r] = (c0 + cl < NC && g >= 0 && g < G) ? tmp[k] : zero4;
+        } else {
+            // LDS-DMA (global_load_lds_dwordx4): one wave instruction moves four consecutive groups of one chunk, 1 KB that is
+            // contiguous in the volume's row and in the tile, without passing through registers.  Groups outside the row
+            // and chunks past the last one are read from the nearest valid address instead of being zeroed: no window
+            // reaches them (arms stop at the image border), so their masks are 0 and any finite value will do.
+            const int NJ = NG >> 2; // NG is a multiple of 4 (the launcher rounds the halo)
+            const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+            for (int idx = wu; idx < 4 * NJ; idx += NW) {
+                const int cl = idx / NJ, j = idx - cl * NJ;
+                const int g = min(max(gbase + 4 * j + ((tid & 63) >> 4), 0), G - 1);
+                const f4 *src = in + ((size_t)min(c0 + cl, NC - 1) * H + y) * G * 16 + g * 16 + (tid & 15);
+                __builtin_amdgcn_global_load_lds((const void *)src, (__attribute__((address_space(3))) void *)(tile + (cl * NG + 4 * j) * 16), 16, 0, 0);
             }
         }
         __syncthreads();
@@ -334,203 +337,192 @@ __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, 
     }
 }
 
-// ------------------------------------------------------------------ both vertical passes, fused
+// ------------------------------------------------------------------ horizontal pass over a volume, streaming (round 3)
+// stm_k_pq_h<.., COST = false> spends most of a block's life waiting: fill the tile (HBM latency), barrier, sweep, exit; three
+// blocks per CU overlap only by chance (round-3 counters: matrix pipe busy 43 % of the time, HBM at 3 TB/s; taking the
+// fill's vector instructions away with LDS-DMA changed nothing).  Here a block owns a whole image row (or a part of one)
+// and walks its segments left to right over a tile that is a RING of groups: a segment's tile shares its 2 HG halo groups
+// with the next one, so only the 4 NW new groups are fetched per segment (every byte of the volume crosses the CU once), and
+// they are already on their way from HBM into REGISTERS (KP float4 per lane) while the waves sweep the current segment; they
+// are written to LDS between the two barriers that end the segment.  Loads and stores are buffer instructions with
+// statically known counts, so the wait for the staged groups leaves the segment's stores in flight.  D <= 64 (one chunk
+// set); masks, MFMA chains and WTA as in stm_k_pq_h.
+// Ring: shifted group index a = group + HG >= 0; piece = 4 groups = 1 KB per chunk; piece a / 4 lives in slot (a / 4) % NJ,
+// NJ = NG / 4.  Segment s uses pieces [8 s', 8 s' + NJ), s' = s NW / 8... (4 NW groups = NW pieces per segment).
+#define STM_BSTORE(rsrc, voff, val) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, val), rsrc, voff, 0, 2)
+template <int NW, bool WTA>
+__global__ __launch_bounds__(64 * NW, (3 * NW) / 4) void stm_k_pq_hs(PQViews v, int D, int zd, int H, int W, int G, int NC, int HG, int nseg, int spl, int dbg)
+{
+    constexpr int TX = 16 * NW, KP = 4; // pixels per segment; new pieces per wave and segment (4 chunks x NW pieces / NW waves)
+    extern __shared__ f4 lds4[];
+    const int NG = 4 * NW + 2 * HG, NJ = NG >> 2;
+    f4 *tile = lds4; // [4 chunks][NJ slots][4 groups][16 hypotheses]
+    uint32_t *sn = (uint32_t *)(tile + 4 * NG * 16);
+    const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lb = l >> 4, dd = l & 15;
+    // block -> (view, row, part of the row)
+    const int part = blockIdx.x % spl, rest = blockIdx.x / spl, y = rest % H, view = rest / H;
+    const int seg_per = (nseg + spl - 1) / spl, seg0 = part * seg_per, seg1 = min(nseg, seg0 + seg_per);
+    if (seg0 >= seg1) return;
+    const f4 *__restrict__ in = (const f4 *)(view ? v.a[1] : v.a[0]);
+    f4 *__restrict__ out = (f4 *)(view ? v.b[1] : v.b[0]);
+    const u8 *__restrict__ armL = view ? v.armL[1] : v.armL[0], *__restrict__ armR = view ? v.armR[1] : v.armR[0];
+    float *__restrict__ disp = view ? v.disp[1] : v.disp[0];
+    const size_t row = (size_t)y * W;
+    const uint32_t rowbytes = (uint32_t)G * 256u;
+    // one row of each chunk; groups outside the row are out of range and read as zeros, chunks past the last are empty buffers
+    __amdgpu_buffer_rsrc_t rin[4], rout[4];
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl) {
+        rin[cl] = __builtin_amdgcn_make_buffer_rsrc((void *)(in + ((size_t)min(cl, NC - 1) * H + y) * G * 16), 0, cl < NC ? rowbytes : 0u, 0x00020000);
+        rout[cl] = __builtin_amdgcn_make_buffer_rsrc((void *)(out + ((size_t)min(cl, NC - 1) * H + y) * G * 16), 0, cl < NC ? rowbytes : 0u, 0x00020000);
+    }
+    f4 st[KP];
+    int aLn = 0, aRn = 0;
+    // piece (chunk cl, shifted piece index pa): groups 4 pa - HG .. + 3 of the row
+#define STM_HS_LOAD(K, CL, PA) st[K] = STM_DBG(dbg, 4) ? f4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin[CL], (4 * (PA) - HG) * 256 + l * 16, 0, 0));
+#define STM_HS_ARMS(S)                                                          \
+    if (tid < TX) {                                                             \
+        const int x = min((S) * TX + tid, W - 1);                               \
+        aLn = armL[row + x];                                                    \
+        aRn = armR[row + x];                                                    \
+    }
+#define STM_HS_SN(S)                                                                                                       \
+    if (tid < TX) {                                                                                                        \
+        const int x = (S) * TX + tid, org = (S) * TX - 4 * HG;                                                             \
+        /* window [x - armL, x + armR) relative to the segment's first tile pixel (d_ca_cross_sum.cu:277-289); past the row: empty */ \
+        sn[tid] = x < W ? ((uint32_t)(x - aLn - org) | ((uint32_t)(aLn + aRn) << 16)) : (uint32_t)(x - org);              \
+    }
+    // first segment: the whole tile, pieces NW seg0 .. NW seg0 + NJ - 1 of every chunk, KP per wave and round
+    {
+        const int np = 4 * NJ;
+        for (int i0 = 0; i0 < np; i0 += NW * KP) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int idx = min(i0 + w + NW * k, np - 1), cl = idx / NJ, j = idx - cl * NJ; // uniform
+                switch (cl) { case 0: STM_HS_LOAD(k, 0, NW * seg0 + j) break; case 1: STM_HS_LOAD(k, 1, NW * seg0 + j) break;
+                              case 2: STM_HS_LOAD(k, 2, NW * seg0 + j) break; default: STM_HS_LOAD(k, 3, NW * seg0 + j) break; }
+            }
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int idx = i0 + w + NW * k, cl = idx / NJ, j = idx - cl * NJ;
+                if (idx < np) tile[(cl * NJ + (NW * seg0 + j) % NJ) * 64 + l] = st[k];
+            }
+        }
+        STM_HS_ARMS(seg0)
+        STM_HS_SN(seg0)
+    }
+    __syncthreads();
+    int slot0 = (NW * seg0) % NJ; // ring slot of the segment's first piece
+    for (int sq = seg0; sq < seg1; ++sq) {
+        const int X0 = sq * TX + 16 * w;
+        const bool more = sq + 1 < seg1;
+        // the NW new pieces per chunk of the next segment: piece index NW (sq + 1) + NJ - NW + jn; wave w takes (chunk k, jn = w)
+        if (more) {
+            const int pa = NW * (sq + 1) + NJ - NW + w;
+            STM_HS_LOAD(0, 0, pa) STM_HS_LOAD(1, 1, pa) STM_HS_LOAD(2, 2, pa) STM_HS_LOAD(3, 3, pa)
+            STM_HS_ARMS(sq + 1)
+        }
+        if (X0 < W) { // uniform per wave
+            const uint32_t e = sn[16 * w + dd]; // mask lanes: pixel dd of the wave
+            const int srel = (int)(e & 0xffffu), nn = (int)(e >> 16);
+            const int G0r = wave_min_i(nn ? (srel >> 2) : 0x7fffffff);
+            const int Gend = wave_max_i(nn ? ((srel + nn + 3) >> 2) : -0x7fffffff);
+            const int n_it = STM_DBG(dbg, 1) ? 0 : STM_DBG(dbg, 2) ? 11 : Gend - G0r; // <= 0 when every window of the wave is empty
+            f16v acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            if (n_it > 0) {
+                int gs = 4 * slot0 + G0r; // ring position (in groups) of the first group of the sweep
+                if (gs >= NG) gs -= NG;
+                const f4 *p = tile + (lb * NG + gs) * 16 + dd;
+                int t = 4 * G0r + lb - srel;
+                for (int it = 0; it < n_it; ++it) {
+                    const f4 c4 = *p;
+                    p += 16;
+                    if (++gs == NG) { gs = 0; p -= NG * 16; } // uniform
+                    const float m = ((unsigned)t < (unsigned)nn) ? 1.0f : 0.0f;
+                    t += 4;
+                    acc = STM_MFMA16(m, c4.x, acc, 0);
+                    acc = STM_MFMA16(m, c4.y, acc, 1);
+                    acc = STM_MFMA16(m, c4.z, acc, 2);
+                    acc = STM_MFMA16(m, c4.w, acc, 3);
+                }
+            }
+            // registers 4b..4b+3 of lane 16q + n = out[pixels X0 + 4q .. +3][hypothesis 16 b + n]
+            if (!WTA) {
+#pragma unroll
+                for (int cl = 0; cl < 4; ++cl) { // groups past the row, chunks past the last: out of range, dropped
+                    const f4 o = {acc[4 * cl], acc[4 * cl + 1], acc[4 * cl + 2], acc[4 * cl + 3]};
+                    STM_BSTORE(rout[cl], (X0 >> 2) * 256 + l * 16, o);
+                }
+            } else {
+                // first strictly-lowest cost wins, ascending d (d_dc_wta.cu:19-34): per lane the chunks come in ascending d
+                float bc[4];
+                int bd[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { bc[i] = 3.402823466e+38f; bd[i] = 0; }
+#pragma unroll
+                for (int cl = 0; cl < 4; ++cl) {
+                    const int d = cl * 16 + dd;
+                    if (d < D) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (bc[i] > acc[4 * cl + i]) { bc[i] = acc[4 * cl + i]; bd[i] = d; }
+                    }
+                }
+                // across the 16 lanes (hypotheses n) of a pixel quad: lowest cost, ties to the lowest d
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(disp + row), 0, (uint32_t)W * 4u, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float m = bc[i];
+                    m = fminf(m, row_ror_f<8>(m));
+                    m = fminf(m, row_ror_f<4>(m));
+                    m = fminf(m, row_ror_f<2>(m));
+                    m = fminf(m, row_ror_f<1>(m));
+                    int cand = (bc[i] == m) ? bd[i] : 0x7fffffff;
+                    cand = min(cand, row_ror_i<8>(cand));
+                    cand = min(cand, row_ror_i<4>(cand));
+                    cand = min(cand, row_ror_i<2>(cand));
+                    cand = min(cand, row_ror_i<1>(cand));
+                    // lane dd == 0 of each pixel quad stores; the other lanes and pixels past the row are out of range
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (float)cand - (float)zd), rs,
+                                                          dd == 0 ? (X0 + 4 * lb + i) * 4 : (int)0x7ffffff0, 0, 0);
+                }
+            }
+        }
+        __syncthreads(); // every wave is done reading the tile
+        if (more) {
+            // the new pieces replace the NW oldest: slots slot0 .. slot0 + NW - 1 (mod NJ); wave w writes slot slot0 + w of every chunk
+            int sl = slot0 + w;
+            if (sl >= NJ) sl -= NJ;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) tile[(k * NJ + sl) * 64 + l] = st[k];
+            STM_HS_SN(sq + 1)
+            slot0 += NW;
+            if (slot0 >= NJ) slot0 -= NJ;
+        }
+        __syncthreads();
+    }
+#undef STM_HS_LOAD
+#undef STM_HS_ARMS
+#undef STM_HS_SN
+}
+
+// ------------------------------------------------------------------ both vertical passes, fused, table-driven
 // One block = one strip of 4 columns (one group) x one chunk of 16 hypotheses, 2 NTP waves: waves 0..NTP-1 run the first
 // vertical pass, 16 output rows each per step, from LDS ring 1 (rows of the input volume) into LDS ring 2; waves NTP..2NTP-1
 // run the second pass LAG steps behind, from ring 2 to HBM.  The intermediate volume never leaves the CU (8 V per frame
-// instead of 12 V).  NTP = 3: a step is 48 rows, so the second ring needs a lag of only 2 steps and two blocks = 12 waves
-// fit a CU's LDS; with one tile per pass and step it was 6 waves and the dependent MFMA chains ran at a third of their rate.
-// Wave tile = 16 rows x 4 columns x 16 hypotheses: lane l: rt = l / 16 (row tile of 4), dq = (l / 4) % 4, i = l % 4; the four
-// column chains take the four components of each ring float4.  Window of pixel (y, x): rows [y - armU, y + armD).
-// Every global access of a step is issued one step ahead (input rows and the next tile's arm bytes) and the LDS reads of
-// the window loop one iteration ahead.
-struct ArmWords { uint32_t u, d; }; // armU / armD bytes of the lane's row, columns 4g..4g+3
-typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-// One dword load per plane, always issued (row clamped; when W % 4 != 0 the address is not dword-aligned and the last group's
-// bytes beyond column W - 1 belong to the next row -- they are masked by the caller, and the workspace slab extends past
-// the last plane): the loads of a step must be unconditional for the compiler to count them in its s_waitcnt.
-__device__ __forceinline__ ArmWords load_arm_words(const u8 *__restrict__ armU, const u8 *__restrict__ armD, int yy, int g, int H, int W)
-{
-    const size_t p = (size_t)min(yy, H - 1) * W + 4 * g;
-    ArmWords a;
-    a.u = *(const u32_unaligned *)(armU + p);
-    a.d = *(const u32_unaligned *)(armD + p);
-    return a;
-}
-
-// One wave tile = 16 rows x 4 columns x 16 hypotheses = ONE v_mfma_f32_16x16x1_4B_f32 per window row: block b = column,
-// A[m] = mask of pixel (row m, column b) (lane 16 b + m), B[n] = cost of hypothesis n at (window row, column b) (lane 16 b + n),
-// D: register 4b + i of lane 16q + n = out[row 4q + i][column b][hypothesis n].  `ring`: rows of float [4 columns][16 hyp.].
-// Window of the lane's pixel: [s0, s0 + nn).  Returns the 16 accumulators.
-__device__ __forceinline__ f16v v12_window_sums(const float *ring, int R, int slot_rd, int y0, int s0, int nn, int l, int dbg)
-{
-    const int lo = wave_min_i(nn ? s0 : 0x7fffffff);
-    const int hi = wave_max_i(nn ? s0 + nn : -0x7fffffff);
-    f16v acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    if (hi > lo && !(dbg & 1)) {
-        const int K0 = lo & ~3; // multiple of 4 (two's complement floor), as R is: a 4-row read never wraps
-        const int n_it = (dbg & 2) ? 12 : (hi - K0 + 3) >> 2; // dbg: timing experiments only
-        int tt = K0 - s0;
-        int sl = slot_rd + (K0 - y0); // K0 - y0 in [-usd - 3, 15]
-        if (sl < 0) sl += R;
-        if (sl >= R) sl -= R;
-        const float *p = ring + sl * 64 + l;
-        const float *const pend = ring + R * 64 + l; // this lane's address one ring length on
-        for (int it = 0; it < n_it; ++it) {
-            const float c0 = p[0], c1 = p[64], c2 = p[128], c3 = p[192]; // four window rows
-            p += 256;
-            if (p >= pend) p -= R * 64;
-            const float m0 = ((unsigned)tt < (unsigned)nn) ? 1.0f : 0.0f;
-            const float m1 = ((unsigned)(tt + 1) < (unsigned)nn) ? 1.0f : 0.0f;
-            const float m2 = ((unsigned)(tt + 2) < (unsigned)nn) ? 1.0f : 0.0f;
-            const float m3 = ((unsigned)(tt + 3) < (unsigned)nn) ? 1.0f : 0.0f;
-            tt += 4;
-            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m0, c0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m1, c1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m2, c2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(m3, c3, acc, 0, 0, 0);
-        }
-    }
-    return acc;
-}
-
-// The two passes run in DIFFERENT code paths (both execute the same two barriers per step): the first-pass waves do every
-// global LOAD of the block (input rows two steps ahead, the next tile's arm bytes) and no store, the second-pass waves do
-// every global STORE and no load (they take their windows from a small LDS ring the first-pass waves fill).  s_waitcnt counts
-// loads and stores together, in issue order: with both in one wave, waiting for an old load dragged in that step's
-// freshly issued rows (the compiler cannot count conditional stores) and every step paid the HBM latency.
-template <int NTP>
-__global__ __launch_bounds__(128 * NTP) void stm_k_pq_v12(PQViews v, int H, int W, int G, int NC, int usd, int R1, int R2, int LAG, int dbg)
-{
-    constexpr int PV_TS = 16 * NTP, NTH = 128 * NTP, LB = 4 * NTP; // rows per step, threads, rows per load batch (first-pass waves)
-    extern __shared__ float ldsf[];
-    // rings of rows; a row = float [4 columns][16 hypotheses] (256 B): lane 16 b + n of a wave reads its B operand linearly
-    float *ring1 = ldsf, *ring2 = ldsf + R1 * 64;
-    int2 *wring = (int2 *)(ldsf + (R1 + R2) * 64); // [LAG + 1][NTP][64]: windows (s0, nn) of the tiles of the last LAG + 1 steps
-    const int view = blockIdx.z, c = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
-    const f4 *__restrict__ in = (const f4 *)(view ? v.b[1] : v.b[0]) + ((size_t)c * H * G + g) * 16;
-    f4 *__restrict__ out = (f4 *)(view ? v.a[1] : v.a[0]) + ((size_t)c * H * G + g) * 16;
-    const u8 *__restrict__ armU = view ? v.armU[1] : v.armU[0], *__restrict__ armD = view ? v.armD[1] : v.armD[0];
-    const size_t rstride = (size_t)G * 16; // float4 elements between consecutive rows of the strip
-    for (int i = tid; i < (R1 + R2) * 64; i += NTH) ldsf[i] = 0.f; // masked steps multiply ring contents by 0: keep them finite
-
-    const int l = tid & 63, wv = (tid >> 6) >= NTP, ti = (tid >> 6) - (wv ? NTP : 0); // pass, tile of the step
-    const int lb = l >> 4, dd = l & 15; // A: column / row;  B: column / hypothesis;  D: row quad / hypothesis
-    const int nT = (H + 15) >> 4, nS = (nT + NTP - 1) / NTP; // tiles of 16 rows, steps
-    __syncthreads();
-    if (!wv) {
-        // ---------------------------------------------------------------- first pass: ring 1 -> ring 2, all loads
-        const int lrow = tid >> 4; // 0 .. 4 NTP - 1: the strip's row r is one 256-B piece, 16 lanes each
-        // rows needed by step 0: [0, TS + usd - 1); four loads in flight per thread
-        int loaded = min(PV_TS + usd - 1, H);
-        for (int r0 = 0; r0 < loaded; r0 += 4 * LB) {
-            f4 tmp[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) tmp[k] = nt_load4(in + (size_t)min(r0 + LB * k + lrow, H - 1) * rstride + dd);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = r0 + LB * k + lrow;
-                if (r < loaded) {
-                    float *q = ring1 + (r % R1) * 64 + dd;
-                    q[0] = tmp[k].x; q[16] = tmp[k].y; q[32] = tmp[k].z; q[48] = tmp[k].w;
-                }
-            }
-        }
-        int slot_ld = loaded % R1; // ring-1 slot of row `loaded`
-        // input rows travel two steps ahead of their use (HBM latency under load exceeds one step): `pre` holds the rows the
-        // NEXT step adds (issued one step ago, written to the ring at the end of this step), `far` those of the step after
-        f4 pre[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pre[k] = nt_load4(in + (size_t)min(loaded + LB * k + lrow, H - 1) * rstride + dd);
-        int u = ti; // this wave's tile of step t: u = NTP t + ti
-        int slot_rd = (16 * ti) % R1, slot_wr = (16 * ti) % R2;
-        // arm bytes: every lane fetches the dword (columns 4g..4g+3) of row (lane % 16) and keeps the byte of its column
-        ArmWords nxt = load_arm_words(armU, armD, u * 16 + dd, g, H, W);
-        int s0, nn;
-#define STM_V_DECODE(U)                                                                                  \
-    {                                                                                                    \
-        const int yy_ = (U) * 16 + dd;                                                                   \
-        const int aU_ = (int)((nxt.u >> (8 * lb)) & 0xffu), aD_ = (int)((nxt.d >> (8 * lb)) & 0xffu);    \
-        s0 = yy_ - aU_;                               /* window [y - armU, y + armD) */                  \
-        nn = (yy_ < H && 4 * g + lb < W) ? aU_ + aD_ : 0;                                                \
-    }
-        STM_V_DECODE(u)
-        for (int t = 0; t < nS + LAG; ++t, u += NTP) {
-            __syncthreads(); // ring 1 holds the rows of this step
-            const int y0 = u * 16;
-            nxt = load_arm_words(armU, armD, (u + NTP) * 16 + dd, g, H, W);
-            f4 far[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) far[k] = (dbg & 4) ? pre[k] : nt_load4(in + (size_t)min(loaded + PV_TS + LB * k + lrow, H - 1) * rstride + dd);
-            if (u < nT) {
-                wring[((t % (LAG + 1)) * NTP + ti) * 64 + l] = make_int2(s0, nn);
-                const f16v acc = v12_window_sums(ring1, R1, slot_rd, y0, s0, nn, l, dbg);
-                // register 4b + i of lane 16q + n = out[row y0 + 4q + i][column 4g + b][hypothesis 16c + n]
-                int so = slot_wr + 4 * lb; // ring 2's slot of the lane's four output rows
-                if (so >= R2) so -= R2;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (y0 + 4 * lb + i < H) {
-                        float *q = ring2 + (so + i) * 64 + dd;
-                        q[0] = acc[i]; q[16] = acc[4 + i]; q[32] = acc[8 + i]; q[48] = acc[12 + i];
-                    }
-                slot_rd += PV_TS;
-                if (slot_rd >= R1) slot_rd -= R1;
-                slot_wr += PV_TS;
-                if (slot_wr >= R2) slot_wr -= R2;
-            }
-            __syncthreads(); // everyone is done reading ring 1: the oldest TS rows can be replaced
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = loaded + LB * k + lrow;
-                int sw = slot_ld + LB * k + lrow;
-                if (sw >= R1) sw -= R1;
-                if (r < H) {
-                    float *q = ring1 + sw * 64 + dd;
-                    q[0] = pre[k].x; q[16] = pre[k].y; q[32] = pre[k].z; q[48] = pre[k].w;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pre[k] = far[k];
-            STM_V_DECODE(u + NTP)
-            loaded += PV_TS; // keeps advancing past H so that later steps load nothing
-            slot_ld += PV_TS;
-            if (slot_ld >= R1) slot_ld -= R1;
-        }
-#undef STM_V_DECODE
-    } else {
-        // ---------------------------------------------------------------- second pass: ring 2 -> HBM, all stores, LAG steps behind
-        int u = -LAG * NTP + ti;
-        int slot_rd = (16 * ti) % R2;
-        for (int t = 0; t < nS + LAG; ++t, u += NTP) {
-            __syncthreads(); // ring 2 holds the first-pass rows of the steps before
-            if (u >= 0 && u < nT) {
-                const int y0 = u * 16;
-                const int2 w = wring[(((t - LAG) % (LAG + 1)) * NTP + ti) * 64 + l]; // written by the first pass at step t - LAG
-                const f16v acc = v12_window_sums(ring2, R2, slot_rd, y0, w.x, w.y, l, dbg);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = y0 + 4 * lb + i;
-                    if (r < H && !(dbg & 4)) {
-                        const f4 o = {acc[i], acc[4 + i], acc[8 + i], acc[12 + i]};
-                        nt_store4(out + (size_t)r * rstride + dd, o);
-                    }
-                }
-                slot_rd += PV_TS;
-                if (slot_rd >= R2) slot_rd -= R2;
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// ------------------------------------------------------------------ both vertical passes, fused, table-driven (round 3)
-// Same decomposition as stm_k_pq_v12 (block = 4 columns x 16 hypotheses, NTP first-pass waves + NTP second-pass waves, two
-// barriers per step of 16 NTP rows), with everything that is not the window sweep taken out of the vector ALU -- on gfx950
+// instead of 12 V).  Two barriers per step of 16 NTP rows; the two passes run in DIFFERENT code paths: the first-pass waves do
+// every global LOAD of the block and no store, the second-pass waves every STORE and no load (s_waitcnt counts loads and
+// stores together, in issue order).  Wave tile = 16 rows x 4 columns x 16 hypotheses = ONE v_mfma_f32_16x16x1_4B_f32 per
+// window row: block b = column, A[m] = mask of pixel (row m, column b) (lane 16 b + m), B[n] = cost of hypothesis n at
+// (window row, column b) (lane 16 b + n), D: register 4b + i of lane 16q + n = out[row 4q + i][column b][hypothesis n].
+// Window of pixel (y, x): rows [y - armU, y + armD).
+// Round 3 took everything that is not the window sweep out of the vector ALU (round 2's kernel computed masks, window
+// bounds and addresses there: 8.1 VALU instructions per MFMA, profiles/r03_pmc_sq_aggm_round2_build.txt) -- on gfx950
 // the f32 MFMAs run on the SIMD's vector ALU, so every other VALU instruction is time the sweep does not get (round-2
-// counters: 8.1 VALU instructions per MFMA in stm_k_pq_v12, profiles/r03_pmc_sq_aggm.txt):
+// now 2.5 per MFMA, profiles/r03_pmc_sq_aggm.txt):
 //  * the window masks of a tile (16 rows x 4 columns) are the same for the 4 chunk blocks of a strip and for both passes, so
 //    stm_k_vwin_table ballots them ONCE per frame into 64-bit lane masks: the sweep fetches four of them with one
 //    s_load_dwordx8 and forms the A operand with ONE v_cndmask_b32 per MFMA (was add + compare + select per column); the
@@ -572,12 +564,6 @@ __global__ __launch_bounds__(256) void stm_k_vwin_table(PQViews v, uint32_t *__r
         if (l < cnt) mk[base + l] = mine;
     }
 }
-
-typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-#define STM_MASKF(m) (__builtin_amdgcn_inverse_ballot_w64(m) ? 1.0f : 0.0f)
-// 16-byte buffer load, streaming (nt).  The builtin's vector is converted as a whole: indexing its elements directly
-// returned element 0 for every index with this compiler (ROCm 7.2).
-#define STM_BLOAD(rsrc, voff) __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 2))
 
 // Sweep of one tile: quads K0 / 4 .. K0 / 4 + n_it - 1 of a ring of RQ quad slots.  Two register sets (A, B) alternate: the
 // loads of a quad (LDS float4, four masks) are issued while the MFMAs of the quad before run.  LDS and scalar loads share one
@@ -645,7 +631,7 @@ __device__ __forceinline__ f16v v12t_run(V12Sweep &S, int RQ)
 
 template <int NTP>
 __global__ __launch_bounds__(128 * NTP) void stm_k_pq_v12t(PQViews v, const uint32_t *__restrict__ wtab, int rec, int H, int W, int G,
-                                                           int NC, int UQ, int RQ1, int RQ2, int LAG)
+                                                           int NC, int UQ, int RQ1, int RQ2, int LAG, int dbg)
 {
     constexpr int TS = 16 * NTP, TQ = 4 * NTP, NTH = 128 * NTP; // rows, quads per step; threads
     extern __shared__ f4 lds4[];
@@ -666,7 +652,7 @@ __global__ __launch_bounds__(128 * NTP) void stm_k_pq_v12t(PQViews v, const uint
     {                                                                            \
         ctab32 *r_ = trow + (size_t)min(max(U, 0), nT - 1) * tstep;                       \
         K0_ = (int)r_[0];                                                        \
-        NIT_ = (int)r_[1];                                                       \
+        NIT_ = STM_DBG(dbg, 1) ? 0 : STM_DBG(dbg, 2) ? 12 : (int)r_[1];          \
     }
     __syncthreads();
     if (!second) {
@@ -706,7 +692,7 @@ __global__ __launch_bounds__(128 * NTP) void stm_k_pq_v12t(PQViews v, const uint
 #define STM_V12_STEP1(PRE, FAR)                                                                                              \
     {                                                                                                                        \
         __syncthreads(); /* ring 1 holds the rows of this step */                                                            \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) FAR[k] = STM_BLOAD(rin, vo[k] + (ld_q + TQ) * 4 * rsb);                \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) FAR[k] = STM_DBG(dbg, 4) ? PRE[k] : STM_BLOAD(rin, vo[k] + (ld_q + TQ) * 4 * rsb); \
         if (!early) v12t_begin(S, ring1 + l, RQ1, s1, 4 * u, trow + (size_t)min(u, nT - 1) * tstep, K0, n_it);               \
         STM_V12_HDR(u + NTP, K0n, n_itn)                                                                                     \
         if (u < nT) {                                                                                                        \
@@ -767,7 +753,7 @@ __global__ __launch_bounds__(128 * NTP) void stm_k_pq_v12t(PQViews v, const uint
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const f4 o = {acc[i], acc[4 + i], acc[8 + i], acc[12 + i]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, o), rout, vo[i] + ro, 0, 2); // rows >= H: out of range, dropped
+                    if (!STM_DBG(dbg, 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, o), rout, vo[i] + ro, 0, 2); // rows >= H: out of range, dropped
                 }
                 s2 += TQ;
                 if (s2 >= RQ2) s2 -= RQ2;
@@ -783,15 +769,6 @@ __global__ __launch_bounds__(128 * NTP) void stm_k_pq_v12t(PQViews v, const uint
 // ------------------------------------------------------------------ launchers
 size_t pq_volume_floats(int D, int H, int W) { return (size_t)((D + 15) / 16) * H * ((W + 3) / 4) * 64; }
 
-// LDS of the round-2 fused vertical kernel: two rings of (48 + 2 usd) and (48 (LAG + 1) + usd) rows of 256 B
-static size_t v12_smem(int usd, int ntp)
-{
-    const int TS = 16 * ntp;
-    const int R1 = (TS + 2 * usd + 3) & ~3;
-    const int LAG = (usd > 1 ? (usd - 1 + TS - 1) / TS : 0) + 1;
-    const int R2 = (TS * (LAG + 1) + usd + 3) & ~3;
-    return (size_t)(R1 + R2) * 256 + (size_t)(LAG + 1) * ntp * 64 * 8; // + the ring of windows the first pass hands to the second
-}
 // LDS of the table-driven fused vertical kernel: rings of (48 + 2 UQ) and (48 (LAG + 1) + UQ) rows of 256 B, UQ = usd rounded up to 4
 static size_t v12t_smem(int usd)
 {
@@ -820,10 +797,10 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
     const int G = (W + 3) / 4, NC = (D + 15) / 16;
     if (usd > 255) usd = 255;
     constexpr int NW = 8;
-    const int HG = (usd + 3) / 4 + 1, NG = 4 * NW + 2 * HG; // halo groups: ceil(usd / 4) on either side of a segment + 1 for the read-ahead
+    const int HG = ((usd + 3) / 4 + 2) & ~1, NG = 4 * NW + 2 * HG; // halo groups: ceil(usd / 4) on either side of a segment + 1 for the read-ahead, rounded to an even number (the tile is filled four groups at a time)
     const int nseg = cdiv(W, 16 * NW), nblk = ((nseg * H * 2 + 7) / 8) * 8;
     const size_t smem_h = (size_t)4 * NG * 256 + 16 * NW * 4;
-    const int dbgh = (agg_variant() / 100000) % 10;
+    const int dbgh = timing_knobs();
     int pad = zd > D - 1 - zd ? zd : D - 1 - zd;
     pad = (pad < 0 ? 0 : pad) + 15; // + the padded hypotheses of the last chunk
     const size_t smem_cost = smem_h + (size_t)(4 * NG * 4 + 4 * pad + 768 + 72) * 4;
@@ -855,8 +832,8 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
         }
         STM_CHECK_LAUNCH();
     }
-    if ((agg_variant() / 100) % 10 != 1) {
-        // table-driven fused vertical kernel (round 3); the window table is built once per frame for both views
+    {
+        // fused vertical kernel; the window table is built once per frame for both views
         constexpr int NTP = 3, TS = 16 * NTP;
         const int UQ = (usd + 3) & ~3, nT = (H + 15) / 16;
         const int rec = 8 + 8 * ((2 * usd + 21) / 4 + 2); // header + the longest sweep + one quad of read-ahead
@@ -871,33 +848,20 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
         ProfScope p("pq_v12");
         const size_t smem = (size_t)(RQ1 + RQ2) * 1024;
         allow_lds_m((const void *)stm_k_pq_v12t<NTP>, smem);
-        STM_LAUNCH(stm_k_pq_v12t<NTP>, dim3(G, NC, 2), dim3(128 * NTP), smem, stream(), v, tab, rec, H, W, G, NC, UQ, RQ1, RQ2, LAG);
-        STM_CHECK_LAUNCH();
-    } else
-    {
-        ProfScope p("pq_v12");
-        const int ntp = (agg_variant() / 10000000) % 10 ? (agg_variant() / 10000000) % 10 : 3;
-        const int TS = 16 * ntp;
-        const int R1 = (TS + 2 * usd + 3) & ~3;
-        const int LAG = (usd > 1 ? (usd - 1 + TS - 1) / TS : 0) + 1; // the second pass may use first-pass rows of EARLIER steps only
-        const int R2 = (TS * (LAG + 1) + usd + 3) & ~3;
-        const size_t smem = v12_smem(usd, ntp);
-        const int dbg = (agg_variant() / 100000) % 10;
-#define STM_LAUNCH_V12(N)                                                                                                       \
-    {                                                                                                                           \
-        allow_lds_m((const void *)stm_k_pq_v12<N>, smem);                                                                       \
-        STM_LAUNCH(stm_k_pq_v12<N>, dim3(G, NC, 2), dim3(128 * N), smem, stream(), v, H, W, G, NC, usd, R1, R2, LAG, dbg); \
-    }
-        if (ntp == 1) STM_LAUNCH_V12(1)
-        else if (ntp == 2) STM_LAUNCH_V12(2)
-        else if (ntp == 4) STM_LAUNCH_V12(4)
-        else STM_LAUNCH_V12(3)
-#undef STM_LAUNCH_V12
+        STM_LAUNCH(stm_k_pq_v12t<NTP>, dim3(G, NC, 2), dim3(128 * NTP), smem, stream(), v, tab, rec, H, W, G, NC, UQ, RQ1, RQ2, LAG, dbgh);
         STM_CHECK_LAUNCH();
     }
     {
         ProfScope p("pq_hw");
-        if (keep_volume) {
+        const int spl = nseg > 24 ? cdiv(nseg, 16) : 1; // blocks per image row
+        const bool streaming = NC <= 4 && NG / 4 >= NW && (agg_variant() / 10) % 10 != 1; // one chunk set; the ring is at least one segment long
+        if (streaming && keep_volume) {
+            allow_lds_m((const void *)stm_k_pq_hs<NW, false>, smem_h);
+            STM_LAUNCH((stm_k_pq_hs<NW, false>), dim3(2 * H * spl), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, spl, dbgh);
+        } else if (streaming) {
+            allow_lds_m((const void *)stm_k_pq_hs<NW, true>, smem_h);
+            STM_LAUNCH((stm_k_pq_hs<NW, true>), dim3(2 * H * spl), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, spl, dbgh);
+        } else if (keep_volume) {
             allow_lds_m((const void *)stm_k_pq_h<NW, false, false>, smem_h);
             STM_LAUNCH((stm_k_pq_h<NW, false, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, 0);
         } else {

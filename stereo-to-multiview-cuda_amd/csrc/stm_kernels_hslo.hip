@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64 * HH_WPB) void stm_k_hslo_h(HsloArgs a, int D, i
             float cc[DPL], cur[DPL];
 #pragma unroll
             for (int j = 0; j < DPL; ++j) cc[j] = r.c[j][k];
-            if (x == x_first || (dbg & 1)) { // first pixel of the line: Cr(p0, d) = C(p0, d)
+            if (x == x_first || STM_DBG(dbg, 1)) { // first pixel of the line: Cr(p0, d) = C(p0, d)
 #pragma unroll
                 for (int j = 0; j < DPL; ++j) cur[j] = cc[j];
             } else {
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64 * HH_WPB) void stm_k_hslo_h(HsloArgs a, int D, i
         }
 #pragma unroll
         for (int j = 0; j < DPL; ++j)
-            if (!(dbg & 2)) {
+            if (!STM_DBG(dbg, 2)) {
                 // left->right: plain stores (8 % faster than non-temporal ones: right->left starts where this pass ended);
                 // right->left: non-temporal (plain ones slow the vertical pass that follows by 5 %)
                 if (BWD) nt_store4(ap[j] + (size_t)g * gs[j], o[j]);
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void stm_k_hslo_v(HsloArgs a, int D, int zd, i
     auto process = [&](const Row &r, int v) {
         const int y = BWD ? H - 1 - v : v;
         float cur[4][DPL];
-        if (v == 0 || (dbg & 1)) { // first pixel of the four lines
+        if (v == 0 || STM_DBG(dbg, 1)) { // first pixel of the four lines
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void stm_k_hslo_v(HsloArgs a, int D, int zd, i
                 f4 o;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = r.s[j][k] + cur[k][j];
-                if (!(dbg & 2)) nt_store4(ap[j] + (size_t)y * rs[j], o);
+                if (!STM_DBG(dbg, 2)) nt_store4(ap[j] + (size_t)y * rs[j], o);
             }
         } else {
             // C2(p, d) = (((C_lr + C_rl) + C_tb) + C_bt) * 0.25f, then first-lowest-wins WTA (d_dc_wta.cu:19-34).  The scaling
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void stm_k_hslo_v(HsloArgs a, int D, int zd, i
 template <int DPL, int PF>
 void hslo_passes(const HsloArgs &a, int nviews, int D, int zd, int H, int W, int G, int WU, int WP, int PAD)
 {
-    const int dbg = (agg_variant() / 100000) % 10; // timing experiments only (stm_hip.h): 1 = no recurrence, 2 = no stores
+    const int dbg = timing_knobs(); // timing build only (stm_common.h): 1 = no recurrence, 2 = no stores
     {
         ProfScope p("hslo_lr");
         STM_LAUNCH((stm_k_hslo_h<DPL, false, PF>), dim3(cdiv(H, HH_WPB), nviews), dim3(64 * HH_WPB), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD, dbg);

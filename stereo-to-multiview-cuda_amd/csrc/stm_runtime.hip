@@ -267,5 +267,11 @@ int stm_prof_read(const char *kernel, float *total_ms)
     if (total_ms) *total_ms = tot;
     return n;
 }
-void stm_set_agg_variant(int v) { stm::g_agg_variant = v; }
+void stm_set_agg_variant(int v)
+{
+#ifndef STM_TIMING
+    v -= ((v / 100000) % 10) * 100000; // the timing-experiment digit exists in libstm_hip_timing.so only
+#endif
+    stm::g_agg_variant = v;
+}
 }

@@ -21,6 +21,6 @@ for variant in [int(x) for x in sys.argv[1:]]:
     for _ in range(5): dev.d_adcensus_stm(d_sbs, dl, dr, out, p, stages=3)
     torch.cuda.synchronize()
     dev.prof_enable(False)
-    for name in ("pq_cost", "pq_h", "pq_v12", "pq_hw", "agg_h", "agg_v", "agg_hw", "cross_arms", "irv", "bilateral"):
+    for name in ("pq_cost", "pq_h", "pq_vtab", "pq_v12", "pq_hw", "agg_h", "agg_v", "agg_hw", "cross_arms", "irv", "bilateral"):
         n, ms = dev.prof_read(name)
         if n: print("   %-12s %3d launches, avg %.4f ms" % (name, n, ms / n), flush=True)
