@@ -89,7 +89,7 @@ struct Arms {
 struct Dim { const char *name; int v, lo; };
 bool args_ok(const char *fn, std::initializer_list<Dim> dims)
 {
-    clear_failed(); // every entry point starts here: a failure is sticky for one API call only (stm_common.h)
+    if (api_outermost()) clear_failed(); // every entry point starts here: a failure is sticky for one (outermost) API call (stm_common.h)
     for (const Dim &d : dims)
         if (d.v < d.lo) {
             char msg[160];
@@ -592,11 +592,17 @@ struct HostFrameBufs {
     void *p[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t cap[4] = {0, 0, 0, 0};
 };
-thread_local HostFrameBufs g_hfb[16];
+constexpr int HFB_DEVS = 64;
+thread_local HostFrameBufs g_hfb[HFB_DEVS];
 // returns false (error recorded, nothing usable) if an allocation fails
 bool host_frame_bufs(const size_t (&bytes)[4], void *(&out)[4])
 {
-    HostFrameBufs &b = g_hfb[cur_dev() & 15];
+    const int dev = cur_dev();
+    if (dev < 0 || dev >= HFB_DEVS) {
+        fail("adcensus_stm: device index out of range", "cur_dev", __FILE__, __LINE__);
+        return false;
+    }
+    HostFrameBufs &b = g_hfb[dev];
     for (int i = 0; i < 4; ++i) {
         if (bytes[i] > b.cap[i]) {
             if (b.p[i]) {
@@ -619,6 +625,29 @@ bool host_frame_bufs(const size_t (&bytes)[4], void *(&out)[4])
     return true;
 }
 } // namespace
+
+// stm_release_workspace(): a thread that ends frees these together with its workspace
+namespace stm {
+void release_host_frame_bufs()
+{
+    int keep = 0;
+    if (hipGetDevice(&keep) != hipSuccess) return;
+    for (int dev = 0; dev < HFB_DEVS; ++dev) {
+        HostFrameBufs &b = g_hfb[dev];
+        bool any = false;
+        for (int i = 0; i < 4; ++i) any = any || b.p[i];
+        if (!any) continue;
+        STM_CHECK(hipSetDevice(dev));
+        STM_CHECK(hipDeviceSynchronize());
+        for (int i = 0; i < 4; ++i) {
+            if (b.p[i]) STM_CHECK(hipFree(b.p[i]));
+            b.p[i] = nullptr;
+            b.cap[i] = 0;
+        }
+    }
+    STM_CHECK(hipSetDevice(keep));
+}
+} // namespace stm
 
 // =============================================================== whole frame
 // adcensus_stm, d_io.cu:7-238: demux -> cost init -> aggregation (L, R) -> WTA -> DCC -> IRV x5 ->
@@ -815,6 +844,7 @@ void stm_adcensus_stm_2(unsigned char *img_sbs, float *disp_l, float *disp_r, un
     float *d_dl = (float *)buf[2], *d_dr = (float *)buf[3];
     STM_CHECK(hipMemcpyAsync(d_sbs, img_sbs, sbs_sz, hipMemcpyHostToDevice, stream()));
     STM_CHECK(hipMemsetAsync(d_out, 0, out_sz, stream()));
+    ApiNest nest; // the device flavour must not forget a failed upload
     stm_d_adcensus_stm_2(d_sbs, d_dl, d_dr, d_out, num_rows, num_cols_sbs, num_cols, num_rows_out, num_cols_out, num_rows_disp,
                          num_cols_disp, elem_sz, disp_scale, num_views, angle, num_disp, zero_disp, ad_coeff, census_coeff, ucd,
                          lcd, usd, lsd, thresh_s, thresh_h);
@@ -862,6 +892,7 @@ void stm_adcensus_stm(unsigned char *img_sbs, float *disp_l, float *disp_r, unsi
     float *d_dl = (float *)buf[2], *d_dr = (float *)buf[3];
     STM_CHECK(hipMemcpyAsync(d_sbs, img_sbs, sbs_sz, hipMemcpyHostToDevice, stream()));
     STM_CHECK(hipMemsetAsync(d_out, 0, out_sz, stream()));
+    ApiNest nest; // the device flavour must not forget a failed upload
     stm_d_adcensus_stm(d_sbs, d_dl, d_dr, d_out, num_rows, num_cols_sbs, num_cols, num_rows_out, num_cols_out, elem_sz,
                        num_views, angle, num_disp, zero_disp, ad_coeff, census_coeff, ucd, lcd, usd, lsd, thresh_s, thresh_h, 3);
     down(disp_l, d_dl, HW); down(disp_r, d_dr, HW); down(interlaced, d_out, out_sz);

@@ -16,6 +16,9 @@ void fail(const char *what, const char *expr, const char *file, int line);
 // allocation can never turn into a kernel running on a null or stale pointer.  Each API entry point clears the flag.
 bool failed();
 void clear_failed();
+struct ApiNest { ApiNest(); ~ApiNest(); }; // held by an entry point around the entry points it calls
+bool api_outermost();
+void release_host_frame_bufs(); // stm_api.hip: the calling thread's staging buffers of the host-flavour frame calls
 #define STM_CHECK(expr)                                                                  \
     do {                                                                                 \
         hipError_t _e = (expr);                                                          \

@@ -509,6 +509,185 @@ __global__ __launch_bounds__(64 * NW, (3 * NW) / 4) void stm_k_pq_hs(PQViews v, 
 #undef STM_HS_SN
 }
 
+// ------------------------------------------------------------------ first horizontal pass with the costs computed in place, streaming
+// The row walk of stm_k_pq_hs for the cost-computing pass (stm_k_pq_h<.., COST = true> computes the 2 HG halo groups of every
+// segment twice and fills its tile in two uneven rounds): the tile is the same ring of groups, and per segment only the 4 NW
+// NEW groups are computed -- exactly one float4 per lane and chunk, wave w owning new piece w.  The pixels those costs need
+// (own image: the new pixels; other image: the new pixels +- pad) are staged in two alternating LDS buffers, fetched two
+// segments ahead; the costs of segment s + 1 are computed into registers after the sweep of segment s and written to the ring
+// between the two barriers that end the segment.  D <= 64 (one chunk set).
+// C(d, x) = rho_ad(|own(x) - other(x')|_1) + rho_c(ham(cen_own(x), cen_other(x'))), x' = clamp(x + sgn (d - zd)) (SURVEY A-Q6);
+// hypotheses d >= D and pixels outside the row are 0.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void stm_k_pq_hc(PQViews v, int D, int zd, int H, int W, int G, int NC, int HG, int nseg,
+                                                                     int spl, const float *__restrict__ lut_g, int pad, int dbg)
+{
+    constexpr int NT = 64 * NW, TX = 16 * NW, NEWPX = 16 * NW; // threads; pixels per segment = new pixels per segment
+    extern __shared__ f4 lds4[];
+    const int NG = 4 * NW + 2 * HG, NJ = NG >> 2;
+    f4 *tile = lds4; // [4 chunks][NJ slots][4 groups][16 hypotheses]
+    uint32_t *sn = (uint32_t *)(tile + 4 * NG * 16);
+    const int SO = NEWPX + 2 * pad; // other-image pixels staged per segment
+    uint2 *s_own = (uint2 *)(sn + TX), *s_oth = s_own + 2 * NEWPX; // two buffers each: [2][NEWPX], [2][SO]
+    float *s_lut_ad = (float *)(s_oth + 2 * SO), *s_lut_c = s_lut_ad + 768;
+    const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lb = l >> 4, dd = l & 15;
+    const int part = blockIdx.x % spl, rest = blockIdx.x / spl, y = rest % H, view = rest / H;
+    const int seg_per = (nseg + spl - 1) / spl, seg0 = part * seg_per, seg1 = min(nseg, seg0 + seg_per);
+    if (seg0 >= seg1) return;
+    f4 *__restrict__ out = (f4 *)(view ? v.b[1] : v.b[0]);
+    const u8 *__restrict__ armL = view ? v.armL[1] : v.armL[0], *__restrict__ armR = view ? v.armR[1] : v.armR[0];
+    const uint32_t *__restrict__ pk_own = view ? v.pk[1] : v.pk[0], *__restrict__ pk_oth = view ? v.pk[0] : v.pk[1];
+    const uint32_t *__restrict__ cen_own = view ? v.cen[1] : v.cen[0], *__restrict__ cen_oth = view ? v.cen[0] : v.cen[1];
+    const int sgn = view ? -1 : 1;
+    const size_t row = (size_t)y * W;
+    const uint32_t rowbytes = (uint32_t)G * 256u;
+    __amdgpu_buffer_rsrc_t rout[4];
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl)
+        rout[cl] = __builtin_amdgcn_make_buffer_rsrc((void *)(out + ((size_t)min(cl, NC - 1) * H + y) * G * 16), 0, cl < NC ? rowbytes : 0u, 0x00020000);
+    for (int i = tid; i < 768 + 65; i += NT) s_lut_ad[i] = lut_g[i];
+    uint2 so = make_uint2(0, 0), sx = make_uint2(0, 0);
+    int aLn = 0, aRn = 0;
+    f4 cst[4];
+    // pixels for the costs of the groups that start at shifted group A0 (group = A0 - HG): own image NEWPX pixels from
+    // x0 = 4 (A0 - HG), other image the same +- pad, both clamped to the row (clamp-to-edge, d_ci_ad.cu:102)
+#define STM_HC_FETCH(A0)                                                                           \
+    {                                                                                              \
+        const int x0_ = 4 * ((A0) - HG);                                                           \
+        if (tid < NEWPX) {                                                                         \
+            const int gx = min(max(x0_ + tid, 0), W - 1);                                          \
+            so = make_uint2(pk_own[row + gx], cen_own[row + gx]);                                  \
+        }                                                                                          \
+        if (tid < SO) {                                                                            \
+            const int gx = min(max(x0_ - pad + tid, 0), W - 1);                                    \
+            sx = make_uint2(pk_oth[row + gx], cen_oth[row + gx]);                                  \
+        }                                                                                          \
+    }
+#define STM_HC_STAGE(B)                                            \
+    {                                                              \
+        if (tid < NEWPX) s_own[(B) * NEWPX + tid] = so;            \
+        if (tid < SO) s_oth[(B) * SO + tid] = sx;                  \
+    }
+    // costs of new piece w (groups 4 w .. 4 w + 3 from shifted group A0), lane = (group, hypothesis-in-chunk), four chunks
+#define STM_HC_COSTS(B, A0)                                                                                               \
+    {                                                                                                                     \
+        const int gi = 4 * w + lb, x0g = 4 * ((A0) - HG + gi);                                                            \
+        const uint2 *own = s_own + (B) * NEWPX + gi * 4;                                                                  \
+        const uint2 o0 = own[0], o1 = own[1], o2 = own[2], o3 = own[3];                                                   \
+        const bool in0 = x0g >= 0 && x0g < W, in1 = x0g + 1 >= 0 && x0g + 1 < W, in2 = x0g + 2 >= 0 && x0g + 2 < W,       \
+                   in3 = x0g + 3 >= 0 && x0g + 3 < W;                                                                     \
+        _Pragma("unroll") for (int cl = 0; cl < 4; ++cl) {                                                                \
+            const int d = cl * 16 + dd;                                                                                   \
+            f4 val = {0.f, 0.f, 0.f, 0.f};                                                                                \
+            if (d < D) {                                                                                                  \
+                const uint2 *oth = s_oth + (B) * SO + gi * 4 + sgn * (d - zd) + pad;                                      \
+                const uint2 q0 = oth[0], q1 = oth[1], q2 = oth[2], q3 = oth[3];                                           \
+                if (in0) val.x = s_lut_ad[__builtin_amdgcn_sad_u8(o0.x, q0.x, 0u)] + s_lut_c[hamdist_q1(o0.y, q0.y)];     \
+                if (in1) val.y = s_lut_ad[__builtin_amdgcn_sad_u8(o1.x, q1.x, 0u)] + s_lut_c[hamdist_q1(o1.y, q1.y)];     \
+                if (in2) val.z = s_lut_ad[__builtin_amdgcn_sad_u8(o2.x, q2.x, 0u)] + s_lut_c[hamdist_q1(o2.y, q2.y)];     \
+                if (in3) val.w = s_lut_ad[__builtin_amdgcn_sad_u8(o3.x, q3.x, 0u)] + s_lut_c[hamdist_q1(o3.y, q3.y)];     \
+            }                                                                                                             \
+            cst[cl] = val;                                                                                                \
+        }                                                                                                                 \
+    }
+#define STM_HC_ARMS(S)                                                          \
+    if (tid < TX) {                                                             \
+        const int x = min((S) * TX + tid, W - 1);                               \
+        aLn = armL[row + x];                                                    \
+        aRn = armR[row + x];                                                    \
+    }
+#define STM_HC_SN(S)                                                                                                       \
+    if (tid < TX) {                                                                                                        \
+        const int x = (S) * TX + tid, org = (S) * TX - 4 * HG;                                                             \
+        sn[tid] = x < W ? ((uint32_t)(x - aLn - org) | ((uint32_t)(aLn + aRn) << 16)) : (uint32_t)(x - org);              \
+    }
+    // first segment: the whole tile, NW pieces per round (shifted groups 4 NW seg0 + 4 NW r ..)
+    for (int r0 = 0; r0 < NJ; r0 += NW) {
+        const int a0 = 4 * NW * seg0 + 4 * r0;
+        STM_HC_FETCH(a0)
+        __syncthreads(); // the previous round's readers are done with buffer 0 (first round: the tables are being written)
+        STM_HC_STAGE(0)
+        __syncthreads();
+        if (r0 + w < NJ) {
+            STM_HC_COSTS(0, a0)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tile[(k * NJ + (NW * seg0 + r0 + w) % NJ) * 64 + l] = cst[k];
+        }
+    }
+    __syncthreads();
+    // staging of segment seg0 + 1's new groups into buffer (seg0 + 1) & 1, arms of seg0
+    {
+        const int a1 = 4 * NW * (seg0 + 1) + NG - 4 * NW;
+        STM_HC_FETCH(a1)
+        STM_HC_STAGE((seg0 + 1) & 1)
+        STM_HC_ARMS(seg0)
+        STM_HC_SN(seg0)
+    }
+    __syncthreads();
+    int slot0 = (NW * seg0) % NJ; // ring slot of the segment's first piece
+    for (int sq = seg0; sq < seg1; ++sq) {
+        const int X0 = sq * TX + 16 * w;
+        const bool more = sq + 1 < seg1;
+        // pixels for the new groups of segment sq + 2 (consumed after the next segment's sweep), arms of segment sq + 1
+        if (more) {
+            STM_HC_FETCH(4 * NW * (sq + 2) + NG - 4 * NW)
+            STM_HC_ARMS(sq + 1)
+        }
+        if (X0 < W) { // uniform per wave
+            const uint32_t e = sn[16 * w + dd]; // mask lanes: pixel dd of the wave
+            const int srel = (int)(e & 0xffffu), nn = (int)(e >> 16);
+            const int G0r = wave_min_i(nn ? (srel >> 2) : 0x7fffffff);
+            const int Gend = wave_max_i(nn ? ((srel + nn + 3) >> 2) : -0x7fffffff);
+            const int n_it = STM_DBG(dbg, 1) ? 0 : Gend - G0r; // <= 0 when every window of the wave is empty
+            f16v acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            if (n_it > 0) {
+                int gs = 4 * slot0 + G0r; // ring position (in groups) of the first group of the sweep
+                if (gs >= NG) gs -= NG;
+                const f4 *p = tile + (lb * NG + gs) * 16 + dd;
+                int t = 4 * G0r + lb - srel;
+                for (int it = 0; it < n_it; ++it) {
+                    const f4 c4 = *p;
+                    p += 16;
+                    if (++gs == NG) { gs = 0; p -= NG * 16; } // uniform
+                    const float m = ((unsigned)t < (unsigned)nn) ? 1.0f : 0.0f;
+                    t += 4;
+                    acc = STM_MFMA16(m, c4.x, acc, 0);
+                    acc = STM_MFMA16(m, c4.y, acc, 1);
+                    acc = STM_MFMA16(m, c4.z, acc, 2);
+                    acc = STM_MFMA16(m, c4.w, acc, 3);
+                }
+            }
+            // registers 4b..4b+3 of lane 16q + n = out[pixels X0 + 4q .. +3][hypothesis 16 b + n]
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) { // groups past the row, chunks past the last: out of range, dropped
+                const f4 o = {acc[4 * cl], acc[4 * cl + 1], acc[4 * cl + 2], acc[4 * cl + 3]};
+                if (!STM_DBG(dbg, 4)) STM_BSTORE(rout[cl], (X0 >> 2) * 256 + l * 16, o);
+            }
+        }
+        if (more) STM_HC_COSTS((sq + 1) & 1, 4 * NW * (sq + 1) + NG - 4 * NW)
+        __syncthreads(); // every wave is done reading the tile and the staging buffers
+        if (more) {
+            int sl = slot0 + w; // the new pieces replace the NW oldest
+            if (sl >= NJ) sl -= NJ;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tile[(k * NJ + sl) * 64 + l] = cst[k];
+            STM_HC_STAGE(sq & 1) // = (sq + 2) & 1
+            STM_HC_SN(sq + 1)
+            slot0 += NW;
+            if (slot0 >= NJ) slot0 -= NJ;
+        }
+        __syncthreads();
+    }
+#undef STM_HC_FETCH
+#undef STM_HC_STAGE
+#undef STM_HC_COSTS
+#undef STM_HC_ARMS
+#undef STM_HC_SN
+}
+
 // ------------------------------------------------------------------ both vertical passes, fused, table-driven
 // One block = one strip of 4 columns (one group) x one chunk of 16 hypotheses, 2 NTP waves: waves 0..NTP-1 run the first
 // vertical pass, 16 output rows each per step, from LDS ring 1 (rows of the input volume) into LDS ring 2; waves NTP..2NTP-1
@@ -819,7 +998,14 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
         constexpr int NWC = 12;
         const int NGc = 4 * NWC + 2 * HG;
         const size_t smem_c12 = (size_t)4 * NGc * 256 + 16 * NWC * 4 + (size_t)(4 * NGc * 4 + 4 * pad + 768 + 72) * 4;
-        if (fuse_cost && smem_c12 <= 80 * 1024 && (agg_variant() / 1000) % 10 != 1) { // 1000: 128-pixel segments as in the other passes
+        const size_t smem_hc = (size_t)4 * NGc * 256 + 16 * NWC * 4 + (size_t)(2 * 16 * NWC + 2 * (16 * NWC + 2 * pad)) * 8 + (768 + 72) * 4;
+        const int nsegc_ = cdiv(W, 16 * NWC);
+        if (fuse_cost && NC <= 4 && NGc / 4 >= NWC && smem_hc <= 80 * 1024 && 16 * NWC + 2 * pad <= 64 * NWC && (agg_variant() / 1000) % 10 == 0) {
+            // streaming row walk (one chunk set, the staged pixels fit one per thread); 2000: one block per segment as in round 2
+            const int splc = nsegc_ > 24 ? cdiv(nsegc_, 16) : 1;
+            allow_lds_m((const void *)stm_k_pq_hc<NWC>, smem_hc);
+            STM_LAUNCH((stm_k_pq_hc<NWC>), dim3(2 * H * splc), dim3(64 * NWC), smem_hc, stream(), v, D, zd, H, W, G, NC, HG, nsegc_, splc, lut, pad, dbgh);
+        } else if (fuse_cost && smem_c12 <= 80 * 1024 && (agg_variant() / 1000) % 10 != 1) { // 1000: 128-pixel segments as in the other passes
             const int nsegc = cdiv(W, 16 * NWC), nblkc = ((nsegc * H * 2 + 7) / 8) * 8;
             allow_lds_m((const void *)stm_k_pq_h<NWC, false, true>, smem_c12);
             STM_LAUNCH((stm_k_pq_h<NWC, false, true>), dim3(nblkc), dim3(64 * NWC), smem_c12, stream(), v, D, zd, H, W, G, NC, HG, nsegc, dbgh, lut, pad);

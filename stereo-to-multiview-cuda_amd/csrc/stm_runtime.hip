@@ -19,6 +19,12 @@ static thread_local std::string g_last_error;
 static thread_local bool g_failed = false;
 bool failed() { return g_failed; }
 void clear_failed() { g_failed = false; }
+// Entry points nest (the host flavour of a frame call and stm_stream_submit call the device flavour after their own copies):
+// only the OUTERMOST one may clear the sticky flag, or a failed upload would be forgotten by the nested call's argument screen.
+static thread_local int g_api_depth = 0;
+ApiNest::ApiNest() { ++g_api_depth; }
+ApiNest::~ApiNest() { --g_api_depth; }
+bool api_outermost() { return g_api_depth == 0; }
 
 void fail(const char *what, const char *expr, const char *file, int line)
 {
@@ -243,7 +249,11 @@ void stm_set_stream(void *s) { stm::g_stream = (hipStream_t)s; }
 void *stm_get_stream(void) { return (void *)stm::g_stream; }
 void stm_set_error_mode(int m) { stm::g_error_mode = m; }
 const char *stm_last_error(void) { return stm::g_last_error.c_str(); }
-void stm_release_workspace(void) { stm::ws_release(); }
+void stm_release_workspace(void)
+{
+    stm::ws_release();
+    stm::release_host_frame_bufs();
+}
 void stm_prof_enable(int on) { stm::g_prof_on = on < 0 ? 0 : on; }
 void stm_prof_reset(void)
 {

@@ -98,6 +98,7 @@ long stm_stream_submit(void *h, const unsigned char *img_sbs)
     stm_set_stream(f->s_compute);
     stm::ws_private_bind(f->ws);
     auto pipeline = [&]() {
+        stm::ApiNest nest; // a failed upload above must survive the nested call's argument screen
         stm_d_adcensus_stm(s.d_in, s.d_dl, s.d_dr, s.d_out, f->H, f->Wsbs, f->W, f->Hout, f->Wout, f->E, f->N, f->angle, f->D,
                            f->zd, f->ad, f->ce, f->ucd, f->lcd, f->usd, f->lsd, f->thresh_s, f->thresh_h, 3);
     };
