@@ -29,7 +29,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured with a float4 copy)
-AGG_KERNELS = ("pq_cost", "pq_h", "pq_v12", "pq_hw", "agg_h", "agg_v", "agg_hw", "cost_init")
+# f32 issue roof of the chip: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz = 78.6 T adds/s.  On gfx950 the f32-input MFMAs run at
+# exactly the f32 vector rate (MI355X_MICROARCH.md: 64 FLOP/clk/SIMD) ON the vector ALU, so this one number bounds the masked
+# MFMA chains of the matrix-pipe kernels and every other vector instruction they issue.
+ISSUE_PEAK_TADDS = 256 * 4 * 32 * 2.4e9 / 1e12
+AGG_KERNELS = ("pq_cost", "pq_h", "pq_vtab", "pq_v12", "pq_hw", "agg_h", "agg_v", "agg_hw", "cost_init")
+MATRIX_PIPE = ("pq_h", "pq_v12", "pq_hw")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def parse():
@@ -43,6 +49,10 @@ def parse():
     ap.add_argument("--stages", type=int, default=3, help="1 = cost+agg+WTA (config 2), 2 = +refinement (config 3), 3 = full frame; add 256 for HSLO before WTA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--agg-variant", type=int, default=0, help="0 = matrix-pipe aggregation (default), 10000 = vector-ALU kernels")
+    ap.add_argument("--batch", type=int, default=0, help="--gpus N > 1: frames per step (default N, one per rank); rank 0 scatters every "
+                    "step's frames and gathers its outputs INSIDE the timed region, double-buffered (sharding.FrameBatchPipeline)")
+    ap.add_argument("--no-batch-movement", action="store_true", help="--gpus N > 1: inputs resident on every rank before timing (the round-1/2 form)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the two-frames-in-flight and real-content legs")
     return ap.parse_args()
 
 
@@ -64,6 +74,12 @@ def cpu_baseline_and_parity(sbs, p, H, W, D, zd, stages, run_gpu):
     that sample and every output is compared with the oracle's, element by element."""
     from oracle import pyoracle as orc
     orc.build()
+    flags = "-O2 (checker build)"
+    try:  # the timed leg runs the -O3 -march=native build of the same source (BASELINE.md section 3), compiled on this host
+        orc.select(orc.build_fast())
+        flags = "-O3 -march=native -ffp-contract=off"
+    except Exception as e:  # no compiler on the box: fall back to the checker build and say so
+        flags += "; fast build failed: %r" % (e,)
     orc.limit_threads_to_usable_cpus()
     hslo = bool(stages & 0x100)
 
@@ -79,8 +95,8 @@ def cpu_baseline_and_parity(sbs, p, H, W, D, zd, stages, run_gpu):
     dt, part, want = run(rows)
     fps = (1.0 / dt) * (rows / float(H))
     base = {"value": fps, "unit": "frames/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": "full pipeline (oracle/stm_oracle.c, OpenMP) on the top %dx%d rows of the same frame, D=%d: %.1f s wall x %d "
-                      "threads; scaled by %d/%d to whole frames" % (W, rows, D, dt, orc.num_threads(), rows, H)}
+            "sample": "full pipeline (oracle/stm_oracle.c, OpenMP, gcc %s) on the top %dx%d rows of the same frame, D=%d: %.1f s wall x %d "
+                      "threads; scaled by %d/%d to whole frames" % (flags, W, rows, D, dt, orc.num_threads(), rows, H)}
     dl, dr, out = run_gpu(part, rows)
     s = stages & 0xff
     wl, wr = (want["wta_l"], want["wta_r"]) if s == 1 else (want["disp_l"], want["disp_r"])
@@ -88,6 +104,32 @@ def cpu_baseline_and_parity(sbs, p, H, W, D, zd, stages, run_gpu):
               "interlaced_mismatch": int((out != want["interlaced"]).sum()) if s == 3 else None,
               "compared": "%dx%d rows of the benchmarked frame, HIP pipeline vs oracle, every element" % (W, rows)}
     return base, parity
+
+
+def window_stats(L, R, p, H, W):
+    """Sum of window lengths per direction and view, and the bytes of the vertical window table, from the arm planes the
+    GPU itself builds (host API ca_cross on a one-plane volume: cross = UP, DOWN, LEFT, RIGHT)."""
+    from stm_amd import host_api
+    sum_h, sum_v, tab_bytes = 0, 0, 0
+    for img in (L, R):
+        cross, _ = host_api.ca_cross(img, np.zeros((1, H, W), np.float32), p.ucd, p.lcd, p.usd, p.lsd)
+        up, down, left, right = [c.astype(np.int64) for c in cross]
+        sum_h += int((left + right).sum())
+        sum_v += int((up + down).sum())
+        # stm_k_vwin_table: per tile of 16 rows x 4 columns a 32-byte header and 32 bytes per quad of the sweep
+        ys = np.arange(H)[:, None]
+        nn = up + down
+        s0 = np.where(nn > 0, ys - up, 1 << 30)
+        e0 = np.where(nn > 0, ys + down, -(1 << 30))
+        Hp, Wp = (H + 15) // 16 * 16, (W + 3) // 4 * 4
+        S = np.full((Hp, Wp), 1 << 30, np.int64)
+        E = np.full((Hp, Wp), -(1 << 30), np.int64)
+        S[:H, :W], E[:H, :W] = s0, e0
+        S = S.reshape(Hp // 16, 16, Wp // 4, 4).min(axis=(1, 3))
+        E = E.reshape(Hp // 16, 16, Wp // 4, 4).max(axis=(1, 3))
+        nit = np.where(E > S, (E - (S & ~3) + 3) >> 2, 0)
+        tab_bytes += int(32 * nit.size + 32 * nit.sum())
+    return sum_h, sum_v, tab_bytes
 
 
 def main():
@@ -118,27 +160,44 @@ def main():
     zd = D // 2
     p = dev.FrameParams(num_disp=D, zero_disp=zd)  # SURVEY 8d defaults: usd=34, lsd=17, 8 views, angle 18.43
     stm_amd.lib().stm_set_agg_variant(args.agg_variant)
+    moving = world > 1 and not args.no_batch_movement  # the C5 batch path: scatter / gather inside the timed region
+    B = (args.batch if args.batch > 0 else world) if moving else world
+    per_rank = len(sharding.shard_indices(B, rank, world))
 
-    # ---- input batch: one frame per rank, generated on rank 0, broadcast over RCCL (xGMI) -------------
-    batch = torch.zeros(world, H, 2 * W, 3, dtype=torch.uint8, device="cuda")
+    # ---- input batch: generated on rank 0 -------------------------------------------------------------
+    batch = torch.zeros(B, H, 2 * W, 3, dtype=torch.uint8, device="cuda") if (rank == 0 or not moving) else None
     sbs_host = None
     if rank == 0:
         frames = []
-        for r in range(world):
-            f, _ = synth.sbs_frame(H, W, D, zd, seed=synth.SEED + r)
+        for r in range(B):
+            f, _ = synth.sbs_frame(H, W, D, zd, seed=synth.SEED + (r % max(world, 1)))
             frames.append(f)
         sbs_host = frames[0]
         batch.copy_(torch.from_numpy(np.stack(frames)))
-    sharding.broadcast_batch(batch, src=0)
-    mine = sharding.shard_indices(world, rank, world)  # one frame per rank
-    frame = batch[mine[0]].contiguous()
+    if not moving:
+        # inputs resident in HBM on every rank before the timed region: RCCL broadcast of the batch (north_star), one frame per rank
+        sharding.broadcast_batch(batch, src=0)
+        mine = sharding.shard_indices(world, rank, world)
+        frame = batch[mine[0]].contiguous()
 
     dl = torch.zeros(H, W, dtype=torch.float32, device="cuda")
     dr = torch.zeros_like(dl)
     out = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+    pipe = None
+    if moving:
+        pipe = sharding.FrameBatchPipeline(B, (H, 2 * W, 3), torch.uint8,
+                                           {"disp_l": ((H, W), torch.float32), "disp_r": ((H, W), torch.float32), "interlaced": ((H, W, 3), torch.uint8)},
+                                           "cuda", rank, world)
 
-    def step():
-        dev.d_adcensus_stm(frame, dl, dr, out, p, stages=args.stages)
+    def run_frame(fr, outs):
+        dev.d_adcensus_stm(fr, outs["disp_l"], outs["disp_r"], outs["interlaced"], p, stages=args.stages)
+
+    def steps(n):
+        if moving:
+            pipe.run([batch] * n if rank == 0 else None, n, run_frame)
+        else:
+            for _ in range(n):
+                dev.d_adcensus_stm(frame, dl, dr, out, p, stages=args.stages)
 
     def barrier():
         torch.cuda.synchronize()
@@ -152,8 +211,7 @@ def main():
             dev.prof_reset()
             dev.prof_enable(profile)  # HIP events on the launch stream, inside the timed region
         t0 = time.perf_counter()
-        for _ in range(n):
-            step()
+        steps(n)
         barrier()
         dt = time.perf_counter() - t0
         if profile:
@@ -163,9 +221,8 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    for _ in range(args.warmup):
-        step()
-    # the timed region carries events around the aggregation kernels only (3-4 event pairs per frame: the roofline figures
+    steps(args.warmup)
+    # the timed region carries events around the aggregation kernels only (four event pairs per frame: the roofline figures
     # come from them); a second, short run with events around every named kernel gives the per-kernel breakdown
     dt = timed(args.steps, 2)
     kern = {}
@@ -176,12 +233,17 @@ def main():
                 kern[name] = {"launches": n, "avg_ms": ms / n, "total_ms": ms}
     nbreak = min(args.steps, 20)
     timed(nbreak, 1)
-    other = {}
-    if rank == 0:
-        for name in AGG_KERNELS + ("cross_arms", "hslo_classes", "hslo_lr", "hslo_rl", "hslo_tb", "hslo_bt", "hslo_to_pq", "wta", "irv", "bilateral", "gaussian_max", "view_synth", "mux"):
+    ALL_NAMES = AGG_KERNELS + ("cross_arms", "hslo_classes", "hslo_lr", "hslo_rl", "hslo_tb", "hslo_bt", "hslo_to_pq", "wta", "irv", "bilateral",
+                               "gaussian_max", "view_synth", "mux")
+
+    def read_all():
+        res = {}
+        for name in ALL_NAMES:
             n, ms = dev.prof_read(name)
             if n:
-                other[name] = ms / n
+                res[name] = ms / n
+        return res
+    other = read_all() if rank == 0 else {}
     # "wall-clock over >= 100 frames": when the driver asks for fewer steps, a second, un-profiled loop gives it
     n100 = max(100, args.steps)
     dt100 = timed(n100, False) if args.steps < 100 else dt
@@ -189,58 +251,88 @@ def main():
     if rank == 0:
         V = float(D) * H * W * 4
         HW = float(H) * W
+        frames_per_step = B  # whole job
+        my_frames = float(per_rank * args.steps)  # frames behind this rank's kernel records
+        L_host, R_host = np.ascontiguousarray(sbs_host[:, :W]), np.ascontiguousarray(sbs_host[:, W:])
+        sum_h, sum_v, tab_bytes = window_stats(L_host, R_host, p, H, W)
         # algorithmic bytes per launch (compulsory inputs + outputs, each buffer once).  The matrix-pipe kernels
-        # serve BOTH views per launch: pq_h = first horizontal pass; pq_v12 = both vertical passes fused (K2 of SURVEY 8d): V in, V out, 2 arm planes per view;
-        # pq_hw = last pass + WTA: V in, 2 arm planes, disparity out.  Vector-ALU kernels (--agg-variant 10000): as round 1.
+        # serve BOTH views per launch: pq_h = first horizontal pass, computing the initial costs itself (per view four dword
+        # planes -- BGRX + census of both images -- and two arm planes in, V out: SURVEY 8d's K1); pq_vtab = the vertical
+        # window table (four arm planes in, the table out); pq_v12 = both vertical passes fused (K2): V in, V out, 2 arm planes
+        # per view (read through the table); pq_hw = last pass + WTA: V in, 2 arm planes, disparity out.  The frame moves 8 V.
+        # Vector-ALU kernels (--agg-variant 10000): as round 1.
         hslo = bool(args.stages & 0x100)
-        # By default the first pass computes the initial costs itself (no pq_cost launch): per view it reads four dword planes
-        # (BGRX + census of both images) and two arm planes and writes V -- SURVEY 8d's K1; the frame then moves 8 V.
         fused_cost = "pq_cost" not in kern
         alg = {"pq_cost": 2 * V + 16 * HW, "pq_h": 2 * (V + 18 * HW) if fused_cost else 2 * (2 * V + 2 * HW),
-               "pq_v12": 2 * (2 * V + 2 * HW), "pq_hw": 2 * (V + 6 * HW),
+               "pq_vtab": 4 * HW + tab_bytes, "pq_v12": 2 * (2 * V + 2 * HW), "pq_hw": 2 * (V + 6 * HW),
                "agg_h": (2 * V + 2 * HW) if hslo else 2 * (V + 2 * HW + 16 * HW), "agg_v": 2 * V + 2 * HW,
                "agg_hw": 2 * (V + 2 * HW + 4 * HW), "cost_init": 2 * V + 4 * 4 * HW}
+        # useful adds per launch = the reference's own count of float adds (one per window element, d_ca_cross_sum.cu:189-194,
+        # 284-289): D x the sum of the window lengths over both views; pq_v12 does two vertical passes
+        useful = {"pq_h": float(D) * sum_h, "pq_hw": float(D) * sum_h, "pq_v12": 2.0 * D * sum_v}
         traffic_all, traffic_src = {}, None
-        tj = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if os.path.exists(tj) and (H, W, D, args.agg_variant, args.stages) == (1080, 1920, 64, 0, 3):
             traffic_all = json.load(open(tj))
-            traffic_src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 per MI355X_MICROARCH.md)"
+            traffic_src = ("profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, FETCH x2 per "
+                           "MI355X_MICROARCH.md; taken on the commit named in its 'commit' key (profiles/README.md)")
         per_kernel = {}
         for k in AGG_KERNELS:
             if k in kern:
                 ach = alg[k] / (kern[k]["avg_ms"] * 1e-3) / 1e9
-                per_kernel[k] = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": kern[k]["avg_ms"],
-                                 "launches_per_frame": kern[k]["launches"] / float(args.steps), "algorithmic_bytes_per_launch": alg[k],
+                per_kernel[k] = {"bound": "issue" if k in MATRIX_PIPE else "hbm",
+                                 "achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": kern[k]["avg_ms"],
+                                 "launches_per_frame": kern[k]["launches"] / my_frames, "algorithmic_bytes_per_launch": alg[k],
                                  "traffic": traffic_all.get(k, {}).get("traffic_bytes")}
-        agg_names = [k for k in per_kernel if k not in ("pq_cost", "cost_init")]
+                if k in useful:
+                    tadds = useful[k] / (kern[k]["avg_ms"] * 1e-3) / 1e12
+                    per_kernel[k]["issue"] = {"useful_adds_per_launch": useful[k], "achieved_Tadds": tadds, "peak": ISSUE_PEAK_TADDS,
+                                              "frac": tadds / ISSUE_PEAK_TADDS}
+        agg_names = [k for k in per_kernel if k not in ("pq_cost", "cost_init", "pq_vtab")]
         dom = max(agg_names, key=lambda k: kern[k]["total_ms"])
-        stage_ms = sum(kern[k]["total_ms"] for k in per_kernel) / args.steps
-        stage_bytes = sum(alg[k] * kern[k]["launches"] for k in per_kernel) / args.steps
-        roofline = {"bound": "hbm", "kernel": "stm_k_" + dom, "achieved": per_kernel[dom]["achieved"], "peak": HBM_PEAK_GBS,
+        stage_ms = sum(kern[k]["total_ms"] for k in per_kernel) / my_frames
+        stage_bytes = sum(alg[k] * kern[k]["launches"] for k in per_kernel) / my_frames
+        roofline = {"bound": per_kernel[dom]["bound"], "kernel": "stm_k_" + dom + ("t" if dom == "pq_v12" else ""),
+                    "achieved": per_kernel[dom]["achieved"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": per_kernel[dom]["traffic"],
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg[dom],
-                    "avg_launch_ms": kern[dom]["avg_ms"], "kernels": per_kernel,
+                    "avg_launch_ms": kern[dom]["avg_ms"],
+                    "bound_note": "achieved / peak / frac are the HBM figures SURVEY 8d defines (algorithmic bytes / launch time vs 8 TB/s); the roof that "
+                                  "binds the matrix-pipe kernels is the f32 issue rate: see 'issue' (useful adds = one per window element, as the reference "
+                                  "counts them; peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz)",
+                    "issue": per_kernel[dom].get("issue"), "kernels": per_kernel,
                     "agg_stage_ms_per_frame": stage_ms, "agg_stage_GBps": stage_bytes / (stage_ms * 1e-3) / 1e9,
-                    "agg_stage_frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        fps = world * args.steps / dt
+                    "agg_stage_frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "window_sums": {"horizontal": sum_h, "vertical": sum_v, "mean_window_h": sum_h / (2 * HW), "mean_window_v": sum_v / (2 * HW)}}
+        fps = frames_per_step * args.steps / dt
         res = {
             "metric": "stereo->8-view frames/sec @1080p d=64; cost-agg HBM GB/s vs roofline",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%dx%d synthetic stereo frame, D=%d, zd=%d, %s, one frame per GPU per step" % (
+            "config": {"workload": "%dx%d synthetic stereo frame, D=%d, zd=%d, %s, %s" % (
                 W, H, D, zd, {1: "cost init + cross aggregation + WTA (BASELINE config 2)",
                               2: "config 2 + DCC + IRV x5 + bilateral (config 3)",
                               3: "full stereo->8-view frame: cost init + cross aggregation + WTA + DCC/IRV x5/bilateral + 6 DIBR views + interlacing"}[args.stages & 0xff]
-                + (" + scanline optimisation (HSLO) before WTA" if args.stages & 0x100 else "")),
-                       "stages": args.stages, "usd": p.usd, "lsd": p.lsd, "views": p.num_views, "sharding": "frames, 1 per rank",
+                + (" + scanline optimisation (HSLO) before WTA" if args.stages & 0x100 else ""),
+                "one frame per GPU per step" if not moving else "%d frames per step" % B),
+                       "stages": args.stages, "usd": p.usd, "lsd": p.lsd, "views": p.num_views,
+                       "sharding": ("frames, %d per step over %d ranks; rank 0 scatters each step's frames and gathers the outputs (disparities + interlaced "
+                                    "frame) inside the timed region, scatter of step k+1 and gather of step k-1 overlapped with the compute of step k "
+                                    "(sharding.FrameBatchPipeline, RCCL)" % (B, world)) if moving else "frames, 1 per rank, inputs resident before timing",
                        "aggregation": "matrix pipe (stm_kernels_aggm.hip)" if args.agg_variant == 0 else "agg_variant %d" % args.agg_variant},
             "rccl_world_size": rccl_world,
-            "rate_over_100_frames": {"frames": n100, "frames_per_s": world * n100 / dt100, "ms_per_frame": dt100 / n100 * 1e3},
+            "rate_over_100_frames": {"frames": n100 * frames_per_step, "frames_per_s": frames_per_step * n100 / dt100, "ms_per_frame": dt100 / (n100 * frames_per_step) * 1e3},
             "roofline": roofline,
             "kernels_ms": {k: round(v, 4) for k, v in other.items()},
-            "kernels_ms_source": "a separate %d-frame run with HIP events around every named kernel (the timed region keeps events around the aggregation kernels only)" % nbreak,
+            "kernels_ms_source": "a separate %d-step run with HIP events around every named kernel (the timed region keeps events around the aggregation kernels only)" % nbreak,
         }
+        if world == 1 and not args.no_extras:
+            res["rate_two_in_flight"] = two_in_flight(torch, dev, sbs_host, p, H, W, args.stages, max(30, min(args.steps, 100)))
+            rc = real_content(torch, dev, synth, p, H, W, D, zd, args.stages, read_all)
+            if rc:
+                res["real_content"] = rc
+        bad = 0
         if not args.no_cpu_baseline and world == 1:
             def run_gpu(part, rows):
                 d_part = torch.from_numpy(part).cuda()
@@ -251,10 +343,92 @@ def main():
                 torch.cuda.synchronize()
                 return a.cpu().numpy(), b.cpu().numpy(), o.cpu().numpy()
             res["cpu_baseline"], res["parity"] = cpu_baseline_and_parity(sbs_host, p, H, W, D, zd, args.stages, run_gpu)
+            bad = sum(v for k, v in res["parity"].items() if k.endswith("_mismatch") and v)
+            if bad:
+                res["invalid"] = "the HIP pipeline differs from the oracle on the benchmarked frame (%d elements): 'value' is NOT a valid result" % bad
         print(json.dumps(res))
+        if bad:
+            sys.stdout.flush()
+            sys.exit(1)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def two_in_flight(torch, dev, sbs_host, p, H, W, stages, n):
+    """Two frames in flight on one GPU: two host threads, each with its own HIP stream and workspace, feed the same frame
+    pipeline (what stm_stream_* does per buffer slot).  Not `value`: that stays one frame per step."""
+    import threading
+    barrier = threading.Barrier(3)
+    errs = []
+
+    def worker():
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                d_sbs = torch.from_numpy(sbs_host).cuda()
+                a = torch.zeros(H, W, dtype=torch.float32, device="cuda")
+                b = torch.zeros_like(a)
+                o = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+                for _ in range(3):
+                    dev.d_adcensus_stm(d_sbs, a, b, o, p, stages=stages)
+                st.synchronize()
+                barrier.wait()
+                for _ in range(n):
+                    dev.d_adcensus_stm(d_sbs, a, b, o, p, stages=stages)
+                st.synchronize()
+        except Exception as e:  # pragma: no cover
+            errs.append(repr(e))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+    ths = [threading.Thread(target=worker) for _ in range(2)]
+    for t in ths:
+        t.start()
+    try:
+        barrier.wait()
+    except threading.BrokenBarrierError:
+        pass
+    t0 = time.perf_counter()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    if errs:
+        return {"error": errs[0]}
+    return {"frames": 2 * n, "frames_per_s": 2 * n / dt, "ms_per_frame": dt / (2 * n) * 1e3,
+            "how": "two host threads x own stream + workspace, %d frames each, same frame and parameters as 'value'" % n}
+
+
+def real_content(torch, dev, synth, p, H, W, D, zd, stages, read_all):
+    """The same pipeline on real image content: the reference's own img/bud_2 + bud_3 pair (committed as data fixtures under
+    tests/golden/) tiled to the benchmark's size.  Compared with the oracle in tests/test_gpu_fullsize.py."""
+    from stm_amd import bmp_io
+    pl, pr = os.path.join(GOLDEN, "bud_2.bmp"), os.path.join(GOLDEN, "bud_3.bmp")
+    if not (os.path.exists(pl) and os.path.exists(pr)):
+        return None
+    sbs = synth.tiled_sbs_frame(bmp_io.read_bmp(pl), bmp_io.read_bmp(pr), H, W)
+    d_sbs = torch.from_numpy(sbs).cuda()
+    a = torch.zeros(H, W, dtype=torch.float32, device="cuda")
+    b = torch.zeros_like(a)
+    o = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+    for _ in range(5):
+        dev.d_adcensus_stm(d_sbs, a, b, o, p, stages=stages)
+    torch.cuda.synchronize()
+    n = 50
+    t0 = time.perf_counter()
+    for _ in range(n):
+        dev.d_adcensus_stm(d_sbs, a, b, o, p, stages=stages)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dev.prof_reset()
+    dev.prof_enable(1)
+    for _ in range(10):
+        dev.d_adcensus_stm(d_sbs, a, b, o, p, stages=stages)
+    torch.cuda.synchronize()
+    dev.prof_enable(False)
+    return {"frames_per_s": n / dt, "ms_per_frame": dt / n * 1e3, "kernels_ms_real": {k: round(v, 4) for k, v in read_all().items()},
+            "frame": "tests/golden/bud_2.bmp + bud_3.bmp (640x384, the reference's img/ pair) tiled to %dx%d (repeated in x, mirrored in y), D=%d, zd=%d" % (W, H, D, zd)}
 
 
 if __name__ == "__main__":

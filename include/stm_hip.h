@@ -73,6 +73,10 @@ int         stm_prof_read(const char *kernel, float *total_ms);
  * digit N00000 (timing experiments that skip parts of kernels) is ignored here: it exists only in libstm_hip_timing.so,
  * a separate build of the same sources with -DSTM_TIMING (csrc/Makefile, `make timing`). */
 void        stm_set_agg_variant(int v);
+/* dr_irv / d_dr_irv / the frame calls: 0 (default) = the reference's accept rule, (winning bin index + zero_disp) / S > thresh_h
+ * (d_dr_irv.cu:36 -- the bin INDEX, SURVEY A-Q17 iv); 1 = the paper's rule, (winning bin's COUNT) / S > thresh_h (Mei et al.,
+ * region voting).  An addition: the reference has no such switch. */
+void        stm_set_irv_paper_ratio(int on);
 
 /* ------------------------------------------------------- cost init (a1-a7) */
 /* d_ci_adcensus.h:23-25  ci_adcensus  (d_ci_adcensus.cu:188-378) */

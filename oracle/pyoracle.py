@@ -28,6 +28,31 @@ def build(force=False):
     return so
 
 
+def build_fast():
+    """The TIMED build of the same source for bench.py's cpu_baseline leg: -O3 -march=native, still
+    -ffp-contract=off and no fast-math, so results are those of the checker build.  Compiled on the machine that runs it
+    (-march=native must not travel), into the temp directory."""
+    import hashlib
+    import tempfile
+    src = os.path.join(_HERE, "stm_oracle.c")
+    tag = hashlib.sha1(open(src, "rb").read()).hexdigest()[:12]
+    so = os.path.join(tempfile.gettempdir(), "libstm_oracle_fast_%s_%d.so" % (tag, os.getuid()))
+    if not os.path.exists(so):
+        tmp = so + ".%d.tmp" % os.getpid()
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
+                               "-fvisibility=hidden", "-fopenmp", "-o", tmp, src, "-lm"])
+        os.replace(tmp, so)
+    return so
+
+
+def select(so):
+    """Switch this module to another build of the oracle library (bench.py: build_fast())."""
+    global _LIB
+    _LIB = C.CDLL(so)
+    _LIB.orc_mux_y_interval.restype = C.c_float
+    return _LIB
+
+
 def lib():
     global _LIB
     if _LIB is None:

@@ -57,6 +57,7 @@ struct ProfScope {
 };
 
 int agg_variant();
+int irv_paper_ratio(); // stm_set_irv_paper_ratio: accept on count / S instead of the reference's bin index / S (SURVEY A-Q17 iv)
 // Timing experiments (skip loads / sweeps / stores; results NOT valid) exist only in the separate libstm_hip_timing.so
 // (make timing, -DSTM_TIMING): in the product library every STM_DBG test is the constant false and stm_set_agg_variant
 // accepts result-preserving variants only.

@@ -437,17 +437,34 @@ __global__ __launch_bounds__(64 * NW, (3 * NW) / 4) void stm_k_pq_hs(PQViews v, 
                 if (gs >= NG) gs -= NG;
                 const f4 *p = tile + (lb * NG + gs) * 16 + dd;
                 int t = 4 * G0r + lb - srel;
-                for (int it = 0; it < n_it; ++it) {
-                    const f4 c4 = *p;
-                    p += 16;
-                    if (++gs == NG) { gs = 0; p -= NG * 16; } // uniform
-                    const float m = ((unsigned)t < (unsigned)nn) ? 1.0f : 0.0f;
-                    t += 4;
-                    acc = STM_MFMA16(m, c4.x, acc, 0);
-                    acc = STM_MFMA16(m, c4.y, acc, 1);
-                    acc = STM_MFMA16(m, c4.z, acc, 2);
-                    acc = STM_MFMA16(m, c4.w, acc, 3);
+                // two register sets: the LDS read of a group is issued before the MFMAs of the group in front of it
+#define STM_HS_NEXT(C)                                        \
+    {                                                         \
+        C = *p;                                               \
+        p += 16;                                              \
+        if (++gs == NG) { gs = 0; p -= NG * 16; } /* uniform */ \
+    }
+#define STM_HS_MFMA(C)                                                          \
+    {                                                                           \
+        const float m = ((unsigned)t < (unsigned)nn) ? 1.0f : 0.0f;             \
+        t += 4;                                                                 \
+        acc = STM_MFMA16(m, C.x, acc, 0);                                       \
+        acc = STM_MFMA16(m, C.y, acc, 1);                                       \
+        acc = STM_MFMA16(m, C.z, acc, 2);                                       \
+        acc = STM_MFMA16(m, C.w, acc, 3);                                       \
+    }
+                f4 ca, cb;
+                STM_HS_NEXT(ca)
+                int it = 0;
+                for (; it + 2 <= n_it; it += 2) {
+                    STM_HS_NEXT(cb)
+                    STM_HS_MFMA(ca)
+                    STM_HS_NEXT(ca) // on the last trip one group past the sweep: any ring slot, unused
+                    STM_HS_MFMA(cb)
                 }
+                if (it < n_it) STM_HS_MFMA(ca)
+#undef STM_HS_NEXT
+#undef STM_HS_MFMA
             }
             // registers 4b..4b+3 of lane 16q + n = out[pixels X0 + 4q .. +3][hypothesis 16 b + n]
             if (!WTA) {
@@ -648,17 +665,34 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void stm_k_pq_hc(PQViews v, 
                 if (gs >= NG) gs -= NG;
                 const f4 *p = tile + (lb * NG + gs) * 16 + dd;
                 int t = 4 * G0r + lb - srel;
-                for (int it = 0; it < n_it; ++it) {
-                    const f4 c4 = *p;
-                    p += 16;
-                    if (++gs == NG) { gs = 0; p -= NG * 16; } // uniform
-                    const float m = ((unsigned)t < (unsigned)nn) ? 1.0f : 0.0f;
-                    t += 4;
-                    acc = STM_MFMA16(m, c4.x, acc, 0);
-                    acc = STM_MFMA16(m, c4.y, acc, 1);
-                    acc = STM_MFMA16(m, c4.z, acc, 2);
-                    acc = STM_MFMA16(m, c4.w, acc, 3);
+                // two register sets: the LDS read of a group is issued before the MFMAs of the group in front of it
+#define STM_HS_NEXT(C)                                        \
+    {                                                         \
+        C = *p;                                               \
+        p += 16;                                              \
+        if (++gs == NG) { gs = 0; p -= NG * 16; } /* uniform */ \
+    }
+#define STM_HS_MFMA(C)                                                          \
+    {                                                                           \
+        const float m = ((unsigned)t < (unsigned)nn) ? 1.0f : 0.0f;             \
+        t += 4;                                                                 \
+        acc = STM_MFMA16(m, C.x, acc, 0);                                       \
+        acc = STM_MFMA16(m, C.y, acc, 1);                                       \
+        acc = STM_MFMA16(m, C.z, acc, 2);                                       \
+        acc = STM_MFMA16(m, C.w, acc, 3);                                       \
+    }
+                f4 ca, cb;
+                STM_HS_NEXT(ca)
+                int it = 0;
+                for (; it + 2 <= n_it; it += 2) {
+                    STM_HS_NEXT(cb)
+                    STM_HS_MFMA(ca)
+                    STM_HS_NEXT(ca) // on the last trip one group past the sweep: any ring slot, unused
+                    STM_HS_MFMA(cb)
                 }
+                if (it < n_it) STM_HS_MFMA(ca)
+#undef STM_HS_NEXT
+#undef STM_HS_MFMA
             }
             // registers 4b..4b+3 of lane 16q + n = out[pixels X0 + 4q .. +3][hypothesis 16 b + n]
 #pragma unroll

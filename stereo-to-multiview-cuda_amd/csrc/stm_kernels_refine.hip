@@ -113,20 +113,22 @@ struct IrvArgs {
     uint32_t *list[2]; // outlier pixels in raster order; entries are retired in place (IV_ACCEPTED, IV_DEAD)
     int *counts[2];    // counts[v][0] = length of the list
     u8 *dirty[2];      // dirty[v][it][tile]: a pixel of the 64x64 tile was accepted in iteration it
-    // per pixel: histogram bin of a reliable pixel, -1 = outlier (no vote), -2 = reliable with the bin out of range.
+    // per pixel, 16 bits: 1 + histogram bin of a reliable pixel, 0 = reliable with the bin out of range (counts towards the
+    // region's size only), 0xFFFF = outlier (no vote).
     // Two planes: iteration `it` reads plane it & 1 (the state all its votes see, as the reference's separate vote
     // and apply kernels guarantee) and writes the pixels it accepts into the other plane.
-    int16_t *code[2][2];
+    uint16_t *code[2][2];
 };
 constexpr uint32_t IV_ACCEPTED = 0x80000000u; // list entry: pixel accepted in the previous iteration
 constexpr uint32_t IV_DEAD = 0xFFFFFFFFu;     // list entry: nothing left to do
 
 // vote code of one pixel: (int)disp + zero_disp is the histogram bin (d_dr_irv.cu:200-201)
-__device__ __forceinline__ int16_t irv_code(u8 outl, float disp, int zd, int nb)
+constexpr uint32_t IV_NOVOTE = 0xFFFFu;
+__device__ __forceinline__ uint16_t irv_code(u8 outl, float disp, int zd, int nb)
 {
-    if (outl != 0) return (int16_t)-1;
+    if (outl != 0) return (uint16_t)IV_NOVOTE;
     const int b = (int)disp + zd;
-    return (b >= 0 && b < nb) ? (int16_t)b : (int16_t)-2;
+    return (b >= 0 && b < nb) ? (uint16_t)(b + 1) : (uint16_t)0;
 }
 
 // counters + dirty bytes of a frame, cleared by a kernel rather than hipMemsetAsync.  Round 2 saw stm_k_irv_vote fault
@@ -160,8 +162,8 @@ __global__ __launch_bounds__(IC_T) void stm_k_irv_compact(IrvArgs a, uint32_t HW
     if (p + 4 <= HW && ((((uintptr_t)outl) & 3) | (((uintptr_t)disp) & 15)) == 0) {
         w = *(const uint32_t *)(outl + p);
         const float4 d = *(const float4 *)(disp + p);
-        const uint32_t c0 = (uint16_t)irv_code((u8)(w & 0xff), d.x, zd, nb), c1 = (uint16_t)irv_code((u8)((w >> 8) & 0xff), d.y, zd, nb);
-        const uint32_t c2 = (uint16_t)irv_code((u8)((w >> 16) & 0xff), d.z, zd, nb), c3 = (uint16_t)irv_code((u8)(w >> 24), d.w, zd, nb);
+        const uint32_t c0 = irv_code((u8)(w & 0xff), d.x, zd, nb), c1 = irv_code((u8)((w >> 8) & 0xff), d.y, zd, nb);
+        const uint32_t c2 = irv_code((u8)((w >> 16) & 0xff), d.z, zd, nb), c3 = irv_code((u8)(w >> 24), d.w, zd, nb);
         const uint2 cc = make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
         *(uint2 *)(a.code[v][0] + p) = cc; // the code planes are workspace memory: aligned
         *(uint2 *)(a.code[v][1] + p) = cc;
@@ -202,18 +204,8 @@ constexpr int IV_WAVES = 2;     // waves per block
 constexpr int IV_PX_PER_BLOCK = 256; // grid per view = pixels / this (see launch_irv)
 constexpr int IV_U = 4;         // row pairs whose loads are in flight together
 
-// one LDS atomic per voting lane.  Merging equal bins with ballots first was measured slower in both forms tried
-// (unbounded merge loop, and two merge rounds + per-lane fallback): the kernel is instruction-issue bound, not
-// bound by same-address serialisation inside the LDS atomic unit.
-__device__ __forceinline__ void irv_tally(int code, uint32_t *hist, int &total)
-{
-    total += __popcll(__ballot(code != -1));
-    if (code >= 0) atomicAdd(&hist[code], 1u);
-}
-
-// max over the 64 lanes as a scalar, on the DPP path (six v_max_u32 with a DPP operand; max is idempotent, so lanes without
-// a source simply keep their value): the LDS round trips of a shuffle reduction are what this kernel cannot afford -- its
-// waves spend half their time in s_waitcnt
+// max / sum over the 64 lanes as a scalar, on the DPP path (six ALU ops with a DPP operand; lanes without a source keep
+// their value / add 0): the LDS round trips of a shuffle reduction are what this kernel cannot afford
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
     asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
@@ -226,14 +218,31 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
                  : "+v"(v));
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    // rotations inside the rows of 16 (DPP row_ror: every lane ends with its row's sum), then the four rows through readlane
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);
+    return (uint32_t)(__builtin_amdgcn_readlane((int)v, 0) + __builtin_amdgcn_readlane((int)v, 16) + __builtin_amdgcn_readlane((int)v, 32) +
+                      __builtin_amdgcn_readlane((int)v, 48));
+}
 
 // Iteration `it` (0-based): vote (dr_irv_pre_kernel, d_dr_irv.cu:134-220) and apply (dr_irv_kernel_3, :17-43) for
 // every live pixel of the outlier list.
-// One wave per outlier, one region row per wave step (lanes = pixels of the row segment, coalesced), IV_U rows
-// in flight together.  Everything that is uniform over the wave is kept in SGPRs: row arms are fetched once into lanes
-// (already clamped into the image) and broadcast with v_readlane, row offsets are 32-bit scalar arithmetic.  Its waves
-// spend half their time in s_waitcnt, so LDS round trips are avoided (DPP reductions), and the work per outlier is
-// uneven, so the grid is several resident sets of small blocks (launch_irv).
+// One wave per outlier, one region row per wave step (lanes = pixels of the row segment, coalesced), IV_U rows in flight
+// together.  Round 3 (real image content has 6x the synthetic frame's outliers, and the round-2 kernel needed 15 scalar and
+// 8 vector instructions per region row): a row now costs two v_readlane, six vector instructions, a load and an LDS atomic
+// and no scalar arithmetic --
+//  * the lanes of a chunk of 64 region rows hold each row's first-pixel BYTE OFFSET into the code plane and its width; a row
+//    step broadcasts both with v_readlane, adds the lane's own 2 l, loads 16 bits (lanes past the segment read whatever
+//    follows and are discarded by one v_cndmask);
+//  * no ballot / population count / exec masking per row: EVERY lane does the LDS atomic; a lane without a vote (outside the
+//    segment, or on an outlier) adds to a slot of its own behind the histogram, which nothing reads; the region's size S
+//    (d_dr_irv.cu:203, reliable pixels only) is the sum of the histogram, taken once per outlier;
+//  * four copies of the histogram (lane % 4): in smooth regions all lanes vote for one bin and the LDS atomic unit
+//    serialises same-address adds (round-2 counters: 82 % of the LDS-active cycles were such conflicts).
 // Apply in the same kernel: the reference votes for ALL outliers on one state and only then updates it.  Here the
 // votes read code plane `it & 1`, which nothing writes during this launch; an accepted pixel is written to the
 // disparity / outlier maps (no vote reads them) and to the OTHER code plane, and its list entry is tagged
@@ -243,24 +252,34 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // Pruning: an outlier whose cross region saw no accepted pixel in the previous iteration would repeat its
 // previous vote exactly (the vote is a pure function of the region) and be rejected again, so it is skipped;
 // `dirty` holds one byte per 64x64 tile and iteration.
+// paper_ratio: accept on (winning COUNT) / S > thresh_h (Mei et al.) instead of the reference's (winning BIN INDEX) / S
+// (d_dr_irv.cu:36, SURVEY A-Q17 iv); off by default.
 constexpr int IV_TILE = 64;
 __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int it, int thresh_s, float thresh_h, int H, int W,
-                                                                int nb, int zd, int usd, int tiles_x, int tiles_y)
+                                                                int nb, int zd, int usd, int tiles_x, int tiles_y, int paper_ratio)
 {
-    extern __shared__ uint32_t irv_lds[]; // per wave: hist[nb]
+    extern __shared__ uint32_t irv_lds[]; // per wave: uint4 slots[nb + 1 + 64]: slot 0 = "other", 1 + b = bin b, then one per lane
     const int v = blockIdx.y;
     float *__restrict__ disp = a.disp[v];
-    const int16_t *__restrict__ code_pl = a.code[v][it & 1];
-    int16_t *__restrict__ code_nx = a.code[v][(it & 1) ^ 1];
+    const uint16_t *__restrict__ code_pl = a.code[v][it & 1];
+    uint16_t *__restrict__ code_nx = a.code[v][(it & 1) ^ 1];
     const u8 *__restrict__ aL = a.aL[v], *__restrict__ aR = a.aR[v];
     uint32_t *__restrict__ list = a.list[v];
     const u8 *__restrict__ dirty = it > 0 ? a.dirty[v] + (size_t)(it - 1) * tiles_x * tiles_y : nullptr;
     u8 *__restrict__ dirty_out = a.dirty[v] + (size_t)it * tiles_x * tiles_y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t *hist = irv_lds + wave * nb;
+    const int nslot = nb + 1 + 64;
+    uint32_t *hist = irv_lds + wave * nslot * 4;
+    const uint32_t nv_slot = (uint32_t)(nb + 1 + lane);                 // this lane's own no-vote slot
+    const uint32_t sub_addr = (uint32_t)((wave * nslot * 4 + (lane & 3)) * 4); // LDS byte address of copy lane % 4 of slot 0
+    const uint32_t lane2 = 2u * lane;
     const int n = min(a.counts[v][0], H * W); // never past the list (capacity H W), whatever the counter holds
-    for (int i = blockIdx.x * IV_WAVES + wave; i < n; i += gridDim.x * IV_WAVES) {
-        const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[i]);
+    const int stride = gridDim.x * IV_WAVES;
+    int i = blockIdx.x * IV_WAVES + wave;
+    uint32_t entry_next = i < n ? list[i] : IV_DEAD;
+    for (; i < n; i += stride) {
+        const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)entry_next);
+        entry_next = i + stride < n ? list[i + stride] : IV_DEAD; // in flight while this outlier is processed
         if ((entry & ~IV_ACCEPTED) >= (uint32_t)(H * W)) continue; // IV_DEAD, or not a pixel of this frame (stale memory behind a wrong counter)
         if (entry & IV_ACCEPTED) { // accepted by the previous launch: bring this launch's write plane up to date
             if (lane == 0) {
@@ -287,77 +306,72 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
             if (lane < nt) d = dirty[(ty0 + lane / nx) * tiles_x + tx0 + lane % nx];
             if (__ballot(d != 0) == 0) continue; // same region contents as last time -> same vote -> rejected again
         }
-        for (int b = lane; b < nb; b += 64) hist[b] = 0;
+        for (int sl = lane; sl <= nb; sl += 64) *(uint4 *)(hist + sl * 4) = make_uint4(0, 0, 0, 0); // the per-lane slots are never read
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int nrows = cu + cd + 1; // rows gy-cu .. gy+cd inclusive (SURVEY A-Q17 iii)
         const int y_top = gy - cu;
-        int total = 0;
-        for (int jb = 0; jb < nrows; jb += 128) { // 128 rows per outer step covers every usd <= 63 in one go
-            // horizontal arms of the region's rows, fetched once and packed into one register per 64 rows: armL in the low byte,
-            // segment width armL + armR + 1 (<= 511) above it -- both already clamped into the image row (a no-op for consistent
-            // arms), so that the per-row scalar work is an unpack and an add: the kernel is bound by scalar-ALU issue
-            uint32_t packed[2] = {0, 0};
+        for (int jb = 0; jb < nrows; jb += 64) {
+            // lane r of the chunk: row y_top + jb + r; segment [gx - armL, gx + armR] clamped into the image row (a no-op for
+            // consistent arms): byte offset of its first pixel in the code plane, and its width (0 past the region)
+            uint32_t roff = 0;
+            int rw = 0;
+            if (jb + lane < nrows) {
+                const int q = (y_top + jb + lane) * W + gx;
+                const int cl = min((int)aL[q], gx);
+                rw = max(min(cl + (int)aR[q] + 1, W - (gx - cl)), 0);
+                roff = 2u * (uint32_t)(q - cl);
+            }
+            const int jend = min(nrows - jb, 64); // wave-uniform
+            for (int j0 = 0; j0 < jend; j0 += IV_U) {
+                uint32_t cdv[IV_U];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-                if (jb + 64 * h + lane < nrows) {
-                    const int q = (y_top + jb + 64 * h + lane) * W + gx;
-                    const int cl = min((int)aL[q], gx);
-                    const int w = max(min(cl + (int)aR[q] + 1, W - (gx - cl)), 0);
-                    packed[h] = (uint32_t)cl | ((uint32_t)w << 8);
+                for (int u = 0; u < IV_U; ++u) { // the first 64 pixels of IV_U rows: all loads issued before any is consumed
+                    const uint32_t so = (uint32_t)__builtin_amdgcn_readlane((int)roff, j0 + u); // rows past jend: lanes hold 0 / width 0
+                    cdv[u] = *(const uint16_t *)((const char *)code_pl + (so + lane2));
                 }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int jend = min(nrows - jb - 64 * h, 64); // wave-uniform
-                if (jend <= 0) break;
-                const uint32_t src = packed[h]; // rows beyond the region hold 0: zero width, no load
-                int rb = (y_top + jb + 64 * h) * W + gx; // scalar: the anchor's column in the current row
-                for (int j0 = 0; j0 < jend; j0 += IV_U) {
-                    int cdv[IV_U], wd[IV_U], base[IV_U];
-                    int wmax = 0;
-#pragma unroll
-                    for (int u = 0; u < IV_U; ++u) { // first 64 pixels of IV_U rows: all loads issued before any is consumed
-                        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)src, j0 + u);
-                        const int w = (int)(pk >> 8);
-                        wd[u] = w;
-                        wmax = max(wmax, w);
-                        base[u] = rb - (int)(pk & 0xff);
-                        rb += W;
-                        cdv[u] = -1; // -1: no vote (outside the row segment, or an outlier itself)
-                        if (lane < w) cdv[u] = (code_pl + (uint32_t)base[u])[(uint32_t)lane]; // scalar row pointer + loop-invariant lane offset
-                    }
-#pragma unroll
-                    for (int u = 0; u < IV_U; ++u) irv_tally(cdv[u], hist, total);
-                    if (wmax > 64) { // segments wider than 64 pixels (arm sum >= 64): rare
-#pragma unroll
-                        for (int u = 0; u < IV_U; ++u) {
-                            for (int c0 = 64; c0 < wd[u]; c0 += 64) {
-                                int code = -1;
-                                if (c0 + lane < wd[u]) code = code_pl[(uint32_t)base[u] + (uint32_t)(c0 + lane)];
-                                irv_tally(code, hist, total);
-                            }
-                        }
+                for (int u = 0; u < IV_U; ++u) {
+                    const int w = __builtin_amdgcn_readlane(rw, j0 + u);
+                    const uint32_t c = lane < w ? cdv[u] : IV_NOVOTE;
+                    const uint32_t slot = min(c, nv_slot); // a vote (c <= nb) or this lane's own slot
+                    atomicAdd(irv_lds + ((slot * 16u + sub_addr) >> 2), 1u);
+                }
+            }
+            if (__ballot(rw > 64) != 0) { // segments wider than 64 pixels (arm sum >= 64): rare
+                for (int j = 0; j < jend; ++j) {
+                    const int w = __builtin_amdgcn_readlane(rw, j);
+                    const uint32_t so = (uint32_t)__builtin_amdgcn_readlane((int)roff, j);
+                    for (int c0 = 64; c0 < w; c0 += 64) {
+                        uint32_t c = IV_NOVOTE;
+                        if (c0 + lane < w) c = *(const uint16_t *)((const char *)code_pl + (so + 2u * (uint32_t)c0 + lane2));
+                        const uint32_t slot = min(c, nv_slot);
+                        atomicAdd(irv_lds + ((slot * 16u + sub_addr) >> 2), 1u);
                     }
                 }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // first bin with the strictly largest count (d_dr_irv.cu:206-215): max over (count, -bin)
-        uint32_t key = 0;
-        for (int b = lane; b < nb; b += 64) {
-            uint32_t c = hist[b];
-            uint32_t k = (c << 16) | (uint32_t)(0xFFFF - b);
-            if (c != 0 && k > key) key = k;
+        // first bin with the strictly largest count (d_dr_irv.cu:206-215): max over (count, -bin); S = all reliable pixels
+        uint32_t key = 0, tot = 0;
+        for (int sl = lane; sl <= nb; sl += 64) {
+            const uint4 h4 = *(const uint4 *)(hist + sl * 4);
+            const uint32_t c = h4.x + h4.y + h4.z + h4.w;
+            tot += c;
+            const uint32_t k = (c << 16) | (uint32_t)(0xFFFF - (sl - 1));
+            if (sl > 0 && c != 0 && k > key) key = k;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         key = wave_max_u32(key);
+        const int total = (int)wave_sum_u32(tot);
         int max_d = (int)own; // default: own disparity (d_dr_irv.cu:182)
         if (key != 0) max_d = (0xFFFF - (int)(key & 0xFFFF)) - zd;
         // apply (d_dr_irv.cu:32-41): the ratio uses the winning BIN INDEX, not its count (:36, SURVEY A-Q17 iv)
-        if (total > thresh_s && (float)(max_d + zd) / (float)total > thresh_h) {
-            const int16_t nc = irv_code(0, (float)max_d, zd, nb);
+        const float num = paper_ratio ? (float)(key >> 16) : (float)(max_d + zd);
+        if (total > thresh_s && num / (float)total > thresh_h) {
+            const uint16_t nc = irv_code(0, (float)max_d, zd, nb);
             if (lane == 0) {
                 a.outl[v][p] = 0;
                 disp[p] = (float)max_d;
@@ -396,8 +410,8 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
     }
     for (int v = 0; v < nviews; ++v) {
         a.list[v] = Workspace::get<uint32_t>(HW);
-        a.code[v][0] = Workspace::get<int16_t>(HW);
-        a.code[v][1] = Workspace::get<int16_t>(HW);
+        a.code[v][0] = Workspace::get<uint16_t>(HW + 64); // + 64: a row's 64-lane load may run past the last segment (its lanes are discarded)
+        a.code[v][1] = Workspace::get<uint16_t>(HW + 64);
     }
     if (nviews == 1) { a.list[1] = a.list[0]; a.code[1][0] = a.code[0][0]; a.code[1][1] = a.code[0][1]; }
     if (rounds == 0) return; // nothing observable happens (a host-flavour vote without an apply only fills scratch)
@@ -411,7 +425,7 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
     STM_LAUNCH(stm_k_irv_compact, dim3((unsigned)((HW + 4 * IC_T - 1) / (4 * IC_T)), nviews), dim3(IC_T), 0, stream(), a, (uint32_t)HW, zd,
                        nb);
     STM_CHECK_LAUNCH();
-    const size_t smem = (size_t)nb * IV_WAVES * 4;
+    const size_t smem = (size_t)(nb + 1 + 64) * 16 * IV_WAVES; // per wave: four copies of (other, nb bins), one slot per lane
     // Several times more waves than the chip holds (1080p: 8100 blocks of 2 waves per view for 8192 wave slots): the waves walk
     // the list with a fixed stride and outliers differ a lot in work, so freed slots must be refilled by the dispatcher --
     // with exactly one resident grid (1024 blocks of 4 waves) the vote took 0.36 ms per frame, with 4096 such blocks 0.30,
@@ -419,7 +433,7 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
     const int iv_blocks = (int)std::min<size_t>(std::max<size_t>((HW + IV_PX_PER_BLOCK - 1) / IV_PX_PER_BLOCK, 256), 32768);
     for (int it = 0; it < rounds; ++it) {
         STM_LAUNCH(stm_k_irv_vote, dim3(iv_blocks, nviews), dim3(64 * IV_WAVES), smem, stream(), a, it, thresh_s, thresh_h, H,
-                           W, nb, zd, usd, tiles_x, tiles_y);
+                           W, nb, zd, usd, tiles_x, tiles_y, irv_paper_ratio());
         STM_CHECK_LAUNCH();
     }
 }

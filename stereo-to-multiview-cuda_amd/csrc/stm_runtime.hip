@@ -186,6 +186,8 @@ ProfScope::~ProfScope()
 
 static int g_agg_variant = 0;
 int agg_variant() { return g_agg_variant; }
+static int g_irv_paper_ratio = 0;
+int irv_paper_ratio() { return g_irv_paper_ratio; }
 
 // ------------------------------------------------------------------ tables
 // rho(c) = 1 - exp(-c/lambda): d_ci_adcensus.cu:27-34 with inv = 1.0/coeff narrowed (:160).
@@ -277,6 +279,7 @@ int stm_prof_read(const char *kernel, float *total_ms)
     if (total_ms) *total_ms = tot;
     return n;
 }
+void stm_set_irv_paper_ratio(int on) { stm::g_irv_paper_ratio = on ? 1 : 0; }
 void stm_set_agg_variant(int v)
 {
 #ifndef STM_TIMING

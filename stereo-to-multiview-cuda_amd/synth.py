@@ -86,3 +86,23 @@ def sbs_frame(H, W, num_disp, zero_disp, seed=SEED):
     """Side-by-side frame [H][2W][3] as adcensus_stm expects (left half = left view, d_demux_common.cu:16-31)."""
     L, R, off = stereo_pair(H, W, num_disp, zero_disp, seed)
     return np.ascontiguousarray(np.concatenate([L, R], axis=1)), off
+
+
+def tiled_pair(left, right, H, W):
+    """A real-content stereo pair of any size from a small one (the reference's 640x384 img/bud_2 + bud_3): repeated
+    horizontally (keeps the sign of every disparity), mirrored vertically on every other repeat (a vertical flip leaves
+    a rectified pair rectified), cropped to H x W.  The seams are ordinary depth/colour edges; what matters is that arm
+    lengths, outlier density and disparity statistics are those of real content (14.5 % L/R outliers on this pair against
+    2 % on the value-noise frame)."""
+    h, w, _ = left.shape
+    ny, nx = (H + h - 1) // h, (W + w - 1) // w
+
+    def tile(img):
+        rows = [np.concatenate([img if (j % 2 == 0) else img[::-1] for _ in range(nx)], axis=1) for j in range(ny)]
+        return np.ascontiguousarray(np.concatenate(rows, axis=0)[:H, :W])
+    return tile(left), tile(right)
+
+
+def tiled_sbs_frame(left, right, H, W):
+    L, R = tiled_pair(left, right, H, W)
+    return np.ascontiguousarray(np.concatenate([L, R], axis=1))

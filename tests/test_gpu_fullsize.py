@@ -266,3 +266,23 @@ def test_c1_bud_pair_through_the_image_io_stage_chain(gpu_ready, c1):
     views.append(L)
     assert np.array_equal(views[3], g["chain_view_3"])
     assert np.array_equal(api.mux_multiview(views, p["angle"], 384, 640), g["chain_mux"])
+
+
+def test_1080p_real_content_vs_oracle(gpu_ready, orc):
+    """The reference's own img/bud_2 + bud_3 pair (committed data fixtures) tiled to 1920x1080, D=64, zd=32 -- the frame
+    bench.py's `real_content` leg times: real-image arm lengths and 7x the synthetic frame's outlier density (the IRV list
+    and its dirty-tile pruning see a very different load).  Full frame vs the oracle, every element."""
+    import os
+    from conftest import GOLDEN
+    from stm_amd import bmp_io, device_api as dev, synth
+    H, W, D, zd = 1080, 1920, 64, 32
+    L, R = bmp_io.read_bmp(os.path.join(GOLDEN, "bud_2.bmp")), bmp_io.read_bmp(os.path.join(GOLDEN, "bud_3.bmp"))
+    sbs = synth.tiled_sbs_frame(L, R, H, W)
+    assert sbs.shape == (H, 2 * W, 3) and np.array_equal(sbs[:384, :640], L) and np.array_equal(sbs[384:768, :640], L[::-1])
+    p = dev.FrameParams(num_disp=D, zero_disp=zd)
+    want = _oracle(orc, sbs, p, H, W, D, zd)
+    dl, dr, out = _run(sbs, p, 3, H, W)
+    assert np.array_equal(dl, want["disp_l"]) and np.array_equal(dr, want["disp_r"])
+    assert np.array_equal(out, want["interlaced"])
+    dl1, dr1, _ = _run(sbs, p, 1, H, W)
+    assert np.array_equal(dl1, want["wta_l"]) and np.array_equal(dr1, want["wta_r"])

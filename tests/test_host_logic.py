@@ -84,6 +84,61 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _pipeline_worker(rank, world, port, q):
+    """The C5 batch loop (FrameBatchPipeline): scatter of batch k+1 and gather of batch k-1 in flight while batch k computes."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stm_amd import sharding
+    B, NB = 5, 4  # five frames per batch over two ranks (3 + 2), four batches
+    batches = None
+    if rank == 0:
+        batches = [((torch.arange(B * 4 * 6 * 3) * (k + 3)) % 251).to(torch.uint8).reshape(B, 4, 6, 3) for k in range(NB)]
+    pipe = sharding.FrameBatchPipeline(B, (4, 6, 3), torch.uint8, {"rowsum": ((4,), torch.float32), "neg": ((4, 6, 3), torch.uint8)},
+                                       "cpu", rank, world)
+    got = []
+
+    def run_frame(frame, outs):
+        outs["rowsum"].copy_(frame.to(torch.float32).sum(dim=(1, 2)))
+        outs["neg"].copy_(255 - frame)
+
+    pipe.run(batches, NB, run_frame, on_result=lambda k, res: got.append((k, {n: t.clone() for n, t in res.items()})))
+    if rank == 0:
+        ok = [k for k, _ in got] == list(range(NB))
+        for k, res in got:
+            ok = ok and torch.equal(res["rowsum"], batches[k].to(torch.float32).sum(dim=(2, 3))) and torch.equal(res["neg"], 255 - batches[k])
+        q.put(bool(ok))
+    else:
+        assert not got  # outputs are gathered to dst only
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_batch_pipeline_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+
+
+def test_frame_batch_pipeline_single_process():
+    from stm_amd import sharding
+    B, NB = 3, 3
+    batches = [((torch.arange(B * 2 * 2) + k) % 7).to(torch.uint8).reshape(B, 2, 2) for k in range(NB)]
+    pipe = sharding.FrameBatchPipeline(B, (2, 2), torch.uint8, {"twice": ((2, 2), torch.int32)}, "cpu", 0, 1)
+    got = {}
+    pipe.run(batches, NB, lambda f, o: o["twice"].copy_(f.to(torch.int32) * 2), on_result=lambda k, r: got.__setitem__(k, r["twice"].clone()))
+    assert sorted(got) == [0, 1, 2] and all(torch.equal(got[k], batches[k].to(torch.int32) * 2) for k in range(NB))
+
+
 def test_frame_sharding_two_ranks_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
