@@ -128,6 +128,10 @@ void core_ci(const u8 *d_img_l, const u8 *d_img_r, Vol cl, Vol cr, uint32_t *pk_
 // aggregation H, V, V, H (d_ca_cross.cu:255-270 minus the transposes); result ends in `cost`
 void core_agg(Vol cost, Vol scratch, const Arms &a, int D, int H, int W, int usd)
 {
+    if ((agg_variant() / 10000) % 10 != 1 && aggm_supports(usd, H, W)) { // the frame pipeline's matrix-pipe kernels (round 3)
+        launch_aggm_stage(cost, cost, a.up, a.down, a.left, a.right, D, H, W, usd);
+        return;
+    }
     launch_agg_h(cost, scratch, a.left, a.right, D, H, W);
     launch_agg_v(scratch, cost, a.up, a.down, D, H, W, usd);
     launch_agg_v(cost, scratch, a.up, a.down, D, H, W, usd);

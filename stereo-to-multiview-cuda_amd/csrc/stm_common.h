@@ -195,6 +195,10 @@ bool aggm_supports(int usd, int H, int W);
 void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, const float *lut, float *const *vol_a, float *const *vol_b,
                        const u8 *const *armU, const u8 *const *armD, const u8 *const *armL, const u8 *const *armR, float *const *disp,
                        int D, int zd, int H, int W, int usd, bool keep_volume = false);
+// ca_cross / d_ca_cross of one volume in the caller's layout on the matrix-pipe kernels; `out` may be `in`
+void launch_aggm_stage(Vol in, Vol out, const u8 *armU, const u8 *armD, const u8 *armL, const u8 *armR, int D, int H, int W, int usd);
+void launch_to_pq(Vol in, float *pq, int D, int H, int W);         // stm_kernels_hslo.hip
+void launch_from_pq(const float *pq, Vol out, int D, int H, int W); // stm_kernels_aggm.hip
 // HSLO (stm_kernels_hslo.hip)
 void launch_hslo_wta(int nviews, const Vol *cost, const u8 *const *img_a, const u8 *const *img_b, const int *osign,
                      float *const *disp, float T, float H1, float H2, int D, int zd, int H, int W, int elem_sz);

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(PC_TX) void stm_k_pq_cost(PQViews v, const float *_
 // plan), at the price of computing the 2 HG halo groups of every segment twice.
 template <int NW, bool WTA, bool COST>
 __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, int H, int W, int G, int NC, int HG, int nseg, int dbg,
-                                                      const float *__restrict__ lut_g, int pad)
+                                                      const float *__restrict__ lut_g, int pad, int nvw)
 {
     constexpr int NT = 64 * NW, TX = 16 * NW;
     extern __shared__ f4 lds4[];
@@ -154,9 +154,9 @@ __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, 
     // XCD and the shared halo is served by that XCD's L2 instead of being fetched from HBM twice.  Placement only affects speed.
     int view, y, X0seg;
     {
-        const int per_xcd = (nseg * H * 2 + 7) >> 3;
+        const int per_xcd = (nseg * H * nvw + 7) >> 3;
         const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-        if (logical >= nseg * H * 2) return;
+        if (logical >= nseg * H * nvw) return;
         X0seg = (logical % nseg) * TX;
         const int rest = logical / nseg;
         y = rest % H;
@@ -996,6 +996,121 @@ bool aggm_supports(int usd, int H, int W)
     return usd >= 1 && v12t_smem(usd) <= 160 * 1024 && (unsigned long long)H * ((W + 3) / 4) * 256ull < (1ull << 31);
 }
 
+// PQ -> the caller's volume (a table of plane pointers, a slab, or quads): thread = (group g, quad of the chunk); the inverse
+// of stm_k_to_pq (stm_kernels_hslo.hip).  Per plane and quarter-wave a 256-byte row piece.
+template <bool QUAD> __global__ __launch_bounds__(256) void stm_k_from_pq(const f4 *__restrict__ in, Vol out, int D, int H, int W, int G)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, c = blockIdx.z;
+    const int g = t >> 2, q = 4 * c + (t & 3);
+    if (g >= G || 4 * q >= D) return;
+    const f4 *src = in + (((size_t)c * H + y) * G + g) * 16 + 4 * (t & 3);
+    const f4 d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3]; // hypotheses 4q..4q+3, four pixels each
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = 4 * g + k;
+        if (x < W) store_quad<QUAD, false>(out, q, D, (size_t)y * W + x, make_float4(d0[k], d1[k], d2[k], d3[k]));
+    }
+}
+void launch_from_pq(const float *pq, Vol out, int D, int H, int W)
+{
+    const int G = (W + 3) / 4, NC = (D + 15) / 16;
+    if (out.quad) STM_LAUNCH(stm_k_from_pq<true>, dim3(cdiv(4 * G, 256), H, NC), dim3(256), 0, stream(), (const f4 *)pq, out, D, H, W, G);
+    else STM_LAUNCH(stm_k_from_pq<false>, dim3(cdiv(4 * G, 256), H, NC), dim3(256), 0, stream(), (const f4 *)pq, out, D, H, W, G);
+    STM_CHECK_LAUNCH();
+}
+
+// The aggregation chain on PQ volumes for `nviews` views (1 or 2).
+//   from_costs: the first horizontal pass computes the initial costs itself (images -> vol_b), else it reads vol_a;
+//   then both vertical passes (vol_b -> vol_a); then the last horizontal pass, vol_a -> disparities (wta) or -> vol_b.
+static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const float *lut, int D, int zd, int H, int W, int usd)
+{
+    const int G = (W + 3) / 4, NC = (D + 15) / 16;
+    if (usd > 255) usd = 255;
+    constexpr int NW = 8;
+    const int HG = ((usd + 3) / 4 + 2) & ~1, NG = 4 * NW + 2 * HG; // halo groups: ceil(usd / 4) on either side of a segment + 1 for the read-ahead, rounded to an even number (the tile is filled four groups at a time)
+    const int nseg = cdiv(W, 16 * NW), nblk = ((nseg * H * nviews + 7) / 8) * 8;
+    const size_t smem_h = (size_t)4 * NG * 256 + 16 * NW * 4;
+    const int dbgh = timing_knobs();
+    int pad = zd > D - 1 - zd ? zd : D - 1 - zd;
+    pad = (pad < 0 ? 0 : pad) + 15; // + the padded hypotheses of the last chunk
+    const size_t smem_cost = smem_h + (size_t)(4 * NG * 4 + 4 * pad + 768 + 72) * 4;
+    const bool fuse_cost = from_costs && (agg_variant() / 1000000) % 10 != 1; // 1: separate stm_k_pq_cost + volume-reading first pass
+    const int spl = nseg > 24 ? cdiv(nseg, 16) : 1; // blocks per image row of the streaming passes
+    const bool streaming = NC <= 4 && NG / 4 >= NW && (agg_variant() / 10) % 10 != 1; // one chunk set; the ring is at least one segment long
+    if (from_costs && !fuse_cost) {
+        ProfScope p("pq_cost");
+        const size_t smem = (size_t)(2 * PC_TX + 2 * (PC_TX + 2 * pad) + 768 + 72) * 4;
+        allow_lds_m((const void *)stm_k_pq_cost, smem);
+        STM_LAUNCH(stm_k_pq_cost, dim3(cdiv(W, PC_TX), H, nviews), dim3(PC_TX), smem, stream(), v, lut, D, zd, H, W, G, NC, pad);
+        STM_CHECK_LAUNCH();
+    }
+    {
+        ProfScope p("pq_h");
+        // the cost-computing pass works on 192-pixel segments when two such blocks still fit a CU's LDS (24 waves per CU either way)
+        constexpr int NWC = 12;
+        const int NGc = 4 * NWC + 2 * HG;
+        const size_t smem_c12 = (size_t)4 * NGc * 256 + 16 * NWC * 4 + (size_t)(4 * NGc * 4 + 4 * pad + 768 + 72) * 4;
+        const size_t smem_hc = (size_t)4 * NGc * 256 + 16 * NWC * 4 + (size_t)(2 * 16 * NWC + 2 * (16 * NWC + 2 * pad)) * 8 + (768 + 72) * 4;
+        const int nsegc = cdiv(W, 16 * NWC);
+        if (fuse_cost && NC <= 4 && NGc / 4 >= NWC && smem_hc <= 80 * 1024 && 16 * NWC + 2 * pad <= 64 * NWC && (agg_variant() / 1000) % 10 == 0) {
+            // streaming row walk (one chunk set, the staged pixels fit one per thread); 2000: one block per segment as in round 2
+            const int splc = nsegc > 24 ? cdiv(nsegc, 16) : 1;
+            allow_lds_m((const void *)stm_k_pq_hc<NWC>, smem_hc);
+            STM_LAUNCH((stm_k_pq_hc<NWC>), dim3(nviews * H * splc), dim3(64 * NWC), smem_hc, stream(), v, D, zd, H, W, G, NC, HG, nsegc, splc, lut, pad, dbgh);
+        } else if (fuse_cost && smem_c12 <= 80 * 1024 && (agg_variant() / 1000) % 10 != 1) { // 1000: 128-pixel segments as in the other passes
+            const int nblkc = ((nsegc * H * nviews + 7) / 8) * 8;
+            allow_lds_m((const void *)stm_k_pq_h<NWC, false, true>, smem_c12);
+            STM_LAUNCH((stm_k_pq_h<NWC, false, true>), dim3(nblkc), dim3(64 * NWC), smem_c12, stream(), v, D, zd, H, W, G, NC, HG, nsegc, dbgh, lut, pad, nviews);
+        } else if (fuse_cost) {
+            allow_lds_m((const void *)stm_k_pq_h<NW, false, true>, smem_cost);
+            STM_LAUNCH((stm_k_pq_h<NW, false, true>), dim3(nblk), dim3(64 * NW), smem_cost, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, pad, nviews);
+        } else if (streaming) { // vol_a -> vol_b
+            allow_lds_m((const void *)stm_k_pq_hs<NW, false>, smem_h);
+            STM_LAUNCH((stm_k_pq_hs<NW, false>), dim3(nviews * H * spl), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, spl, dbgh);
+        } else {
+            allow_lds_m((const void *)stm_k_pq_h<NW, false, false>, smem_h);
+            STM_LAUNCH((stm_k_pq_h<NW, false, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, 0, nviews);
+        }
+        STM_CHECK_LAUNCH();
+    }
+    {
+        // fused vertical kernel; the window table is built once per call for all views
+        constexpr int NTP = 3, TS = 16 * NTP;
+        const int UQ = (usd + 3) & ~3, nT = (H + 15) / 16;
+        const int rec = 8 + 8 * ((2 * usd + 21) / 4 + 2); // header + the longest sweep + one quad of read-ahead
+        const int LAG = (UQ + TS - 1) / TS + 1;
+        const int RQ1 = (TS + 2 * UQ) / 4, RQ2 = (TS * (LAG + 1) + UQ) / 4;
+        uint32_t *tab = Workspace::get<uint32_t>((size_t)nviews * nT * G * rec);
+        {
+            ProfScope p("pq_vtab");
+            STM_LAUNCH(stm_k_vwin_table, dim3(cdiv(G, 4), nT, nviews), dim3(256), 0, stream(), v, tab, rec, H, W, G, nT);
+            STM_CHECK_LAUNCH();
+        }
+        ProfScope p("pq_v12");
+        const size_t smem = (size_t)(RQ1 + RQ2) * 1024;
+        allow_lds_m((const void *)stm_k_pq_v12t<NTP>, smem);
+        STM_LAUNCH(stm_k_pq_v12t<NTP>, dim3(G, NC, nviews), dim3(128 * NTP), smem, stream(), v, tab, rec, H, W, G, NC, UQ, RQ1, RQ2, LAG, dbgh);
+        STM_CHECK_LAUNCH();
+    }
+    {
+        ProfScope p("pq_hw");
+        if (streaming && !wta) {
+            allow_lds_m((const void *)stm_k_pq_hs<NW, false>, smem_h);
+            STM_LAUNCH((stm_k_pq_hs<NW, false>), dim3(nviews * H * spl), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, spl, dbgh);
+        } else if (streaming) {
+            allow_lds_m((const void *)stm_k_pq_hs<NW, true>, smem_h);
+            STM_LAUNCH((stm_k_pq_hs<NW, true>), dim3(nviews * H * spl), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, spl, dbgh);
+        } else if (!wta) {
+            allow_lds_m((const void *)stm_k_pq_h<NW, false, false>, smem_h);
+            STM_LAUNCH((stm_k_pq_h<NW, false, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, 0, nviews);
+        } else {
+            allow_lds_m((const void *)stm_k_pq_h<NW, true, false>, smem_h);
+            STM_LAUNCH((stm_k_pq_h<NW, true, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, 0, nviews);
+        }
+        STM_CHECK_LAUNCH();
+    }
+}
+
 // cost -> H -> V, V -> H + WTA for both views of a frame.  vol_a / vol_b: two PQ volumes per view (pq_volume_floats each).
 // keep_volume: the last pass writes the aggregated costs to vol_b instead of doing WTA (the HSLO stage follows; disp unused).
 void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, const float *lut, float *const *vol_a, float *const *vol_b,
@@ -1007,89 +1122,24 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
         v.pk[i] = pk[i]; v.cen[i] = cen[i]; v.a[i] = vol_a[i]; v.b[i] = vol_b[i];
         v.armU[i] = armU[i]; v.armD[i] = armD[i]; v.armL[i] = armL[i]; v.armR[i] = armR[i]; v.disp[i] = disp[i];
     }
-    const int G = (W + 3) / 4, NC = (D + 15) / 16;
-    if (usd > 255) usd = 255;
-    constexpr int NW = 8;
-    const int HG = ((usd + 3) / 4 + 2) & ~1, NG = 4 * NW + 2 * HG; // halo groups: ceil(usd / 4) on either side of a segment + 1 for the read-ahead, rounded to an even number (the tile is filled four groups at a time)
-    const int nseg = cdiv(W, 16 * NW), nblk = ((nseg * H * 2 + 7) / 8) * 8;
-    const size_t smem_h = (size_t)4 * NG * 256 + 16 * NW * 4;
-    const int dbgh = timing_knobs();
-    int pad = zd > D - 1 - zd ? zd : D - 1 - zd;
-    pad = (pad < 0 ? 0 : pad) + 15; // + the padded hypotheses of the last chunk
-    const size_t smem_cost = smem_h + (size_t)(4 * NG * 4 + 4 * pad + 768 + 72) * 4;
-    const bool fuse_cost = (agg_variant() / 1000000) % 10 != 1; // 1: separate stm_k_pq_cost + volume-reading first pass
-    if (!fuse_cost) {
-        ProfScope p("pq_cost");
-        const size_t smem = (size_t)(2 * PC_TX + 2 * (PC_TX + 2 * pad) + 768 + 72) * 4;
-        allow_lds_m((const void *)stm_k_pq_cost, smem);
-        STM_LAUNCH(stm_k_pq_cost, dim3(cdiv(W, PC_TX), H, 2), dim3(PC_TX), smem, stream(), v, lut, D, zd, H, W, G, NC, pad);
-        STM_CHECK_LAUNCH();
+    aggm_chain(v, 2, true, !keep_volume, lut, D, zd, H, W, usd);
+}
+
+// The per-stage aggregation (ca_cross / d_ca_cross, d_ca_cross.cu:255-270) of ONE volume in the caller's layout on the
+// matrix-pipe kernels: volume -> PQ, H, V V, H, PQ -> `out` (which may be `in`: the device flavour returns the result in its
+// input volume, SURVEY A-Q11).  Two PQ volumes and the window table come from the current Workspace scope.
+void launch_aggm_stage(Vol in, Vol out, const u8 *armU, const u8 *armD, const u8 *armL, const u8 *armR, int D, int H, int W, int usd)
+{
+    const size_t VP = pq_volume_floats(D, H, W);
+    float *m = Workspace::get<float>(2 * VP);
+    PQViews v;
+    for (int i = 0; i < 2; ++i) {
+        v.pk[i] = nullptr; v.cen[i] = nullptr; v.a[i] = m; v.b[i] = m + VP;
+        v.armU[i] = armU; v.armD[i] = armD; v.armL[i] = armL; v.armR[i] = armR; v.disp[i] = nullptr;
     }
-    {
-        ProfScope p("pq_h");
-        // the cost-computing pass works on 192-pixel segments when two such blocks still fit a CU's LDS (24 waves per CU either
-        // way): the halo, whose costs are computed by both neighbours, shrinks from 0.62 to 0.42 of a segment (0.555 -> 0.453 ms)
-        constexpr int NWC = 12;
-        const int NGc = 4 * NWC + 2 * HG;
-        const size_t smem_c12 = (size_t)4 * NGc * 256 + 16 * NWC * 4 + (size_t)(4 * NGc * 4 + 4 * pad + 768 + 72) * 4;
-        const size_t smem_hc = (size_t)4 * NGc * 256 + 16 * NWC * 4 + (size_t)(2 * 16 * NWC + 2 * (16 * NWC + 2 * pad)) * 8 + (768 + 72) * 4;
-        const int nsegc_ = cdiv(W, 16 * NWC);
-        if (fuse_cost && NC <= 4 && NGc / 4 >= NWC && smem_hc <= 80 * 1024 && 16 * NWC + 2 * pad <= 64 * NWC && (agg_variant() / 1000) % 10 == 0) {
-            // streaming row walk (one chunk set, the staged pixels fit one per thread); 2000: one block per segment as in round 2
-            const int splc = nsegc_ > 24 ? cdiv(nsegc_, 16) : 1;
-            allow_lds_m((const void *)stm_k_pq_hc<NWC>, smem_hc);
-            STM_LAUNCH((stm_k_pq_hc<NWC>), dim3(2 * H * splc), dim3(64 * NWC), smem_hc, stream(), v, D, zd, H, W, G, NC, HG, nsegc_, splc, lut, pad, dbgh);
-        } else if (fuse_cost && smem_c12 <= 80 * 1024 && (agg_variant() / 1000) % 10 != 1) { // 1000: 128-pixel segments as in the other passes
-            const int nsegc = cdiv(W, 16 * NWC), nblkc = ((nsegc * H * 2 + 7) / 8) * 8;
-            allow_lds_m((const void *)stm_k_pq_h<NWC, false, true>, smem_c12);
-            STM_LAUNCH((stm_k_pq_h<NWC, false, true>), dim3(nblkc), dim3(64 * NWC), smem_c12, stream(), v, D, zd, H, W, G, NC, HG, nsegc, dbgh, lut, pad);
-        } else if (fuse_cost) {
-            allow_lds_m((const void *)stm_k_pq_h<NW, false, true>, smem_cost);
-            STM_LAUNCH((stm_k_pq_h<NW, false, true>), dim3(nblk), dim3(64 * NW), smem_cost, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, pad);
-        } else {
-            allow_lds_m((const void *)stm_k_pq_h<NW, false, false>, smem_h);
-            STM_LAUNCH((stm_k_pq_h<NW, false, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, 0);
-        }
-        STM_CHECK_LAUNCH();
-    }
-    {
-        // fused vertical kernel; the window table is built once per frame for both views
-        constexpr int NTP = 3, TS = 16 * NTP;
-        const int UQ = (usd + 3) & ~3, nT = (H + 15) / 16;
-        const int rec = 8 + 8 * ((2 * usd + 21) / 4 + 2); // header + the longest sweep + one quad of read-ahead
-        const int LAG = (UQ + TS - 1) / TS + 1;
-        const int RQ1 = (TS + 2 * UQ) / 4, RQ2 = (TS * (LAG + 1) + UQ) / 4;
-        uint32_t *tab = Workspace::get<uint32_t>((size_t)2 * nT * G * rec);
-        {
-            ProfScope p("pq_vtab");
-            STM_LAUNCH(stm_k_vwin_table, dim3(cdiv(G, 4), nT, 2), dim3(256), 0, stream(), v, tab, rec, H, W, G, nT);
-            STM_CHECK_LAUNCH();
-        }
-        ProfScope p("pq_v12");
-        const size_t smem = (size_t)(RQ1 + RQ2) * 1024;
-        allow_lds_m((const void *)stm_k_pq_v12t<NTP>, smem);
-        STM_LAUNCH(stm_k_pq_v12t<NTP>, dim3(G, NC, 2), dim3(128 * NTP), smem, stream(), v, tab, rec, H, W, G, NC, UQ, RQ1, RQ2, LAG, dbgh);
-        STM_CHECK_LAUNCH();
-    }
-    {
-        ProfScope p("pq_hw");
-        const int spl = nseg > 24 ? cdiv(nseg, 16) : 1; // blocks per image row
-        const bool streaming = NC <= 4 && NG / 4 >= NW && (agg_variant() / 10) % 10 != 1; // one chunk set; the ring is at least one segment long
-        if (streaming && keep_volume) {
-            allow_lds_m((const void *)stm_k_pq_hs<NW, false>, smem_h);
-            STM_LAUNCH((stm_k_pq_hs<NW, false>), dim3(2 * H * spl), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, spl, dbgh);
-        } else if (streaming) {
-            allow_lds_m((const void *)stm_k_pq_hs<NW, true>, smem_h);
-            STM_LAUNCH((stm_k_pq_hs<NW, true>), dim3(2 * H * spl), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, spl, dbgh);
-        } else if (keep_volume) {
-            allow_lds_m((const void *)stm_k_pq_h<NW, false, false>, smem_h);
-            STM_LAUNCH((stm_k_pq_h<NW, false, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, 0);
-        } else {
-            allow_lds_m((const void *)stm_k_pq_h<NW, true, false>, smem_h);
-            STM_LAUNCH((stm_k_pq_h<NW, true, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, 0);
-        }
-        STM_CHECK_LAUNCH();
-    }
+    launch_to_pq(in, m, D, H, W);
+    aggm_chain(v, 1, false, false, nullptr, D, 0, H, W, usd);
+    launch_from_pq(m + VP, out, D, H, W);
 }
 
 } // namespace stm

@@ -475,6 +475,15 @@ void hslo_passes(const HsloArgs &a, int nviews, int D, int zd, int H, int W, int
 
 } // namespace
 
+void launch_to_pq(Vol in, float *pq, int D, int H, int W)
+{
+    const int G = (W + 3) / 4, NC = (D + 15) / 16;
+    if (in.quad) STM_LAUNCH(stm_k_to_pq<true>, dim3(cdiv(4 * G, 256), H, NC), dim3(256), 0, stream(), in, (f4 *)pq, D, H, W, G);
+    else STM_LAUNCH(stm_k_to_pq<false>, dim3(cdiv(4 * G, 256), H, NC), dim3(256), 0, stream(), in, (f4 *)pq, D, H, W, G);
+    STM_CHECK_LAUNCH();
+}
+
+
 // ------------------------------------------------------------------ drivers
 // Scanline optimisation + WTA for 1 or 2 views whose aggregated costs are PQ volumes (pq_volume_floats each).
 // cost_pq[v] is read only; acc_pq[v] is a scratch volume of the same size.

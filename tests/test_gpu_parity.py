@@ -484,8 +484,12 @@ def test_error_mode_records_instead_of_exiting(gpu_ready, stm):
     try:
         L = np.zeros((2, 8200, 3), np.uint8)
         cost = np.zeros((1, 2, 8200), np.float32)
+        lib.stm_set_agg_variant(10000)  # the vector-ALU kernels (the matrix-pipe path of the default build has no such limit)
         host_api.ca_cross(L, cost, 6.0, 20.0, 3, 1)  # num_cols > 8192 is rejected by the row-tile kernel
+        lib.stm_set_agg_variant(0)
         assert b"8192" in lib.stm_last_error()
+        cross, acost = host_api.ca_cross(L, cost, 6.0, 20.0, 3, 1)  # default path: works, and sums of zeros are zeros
+        assert acost.shape == cost.shape and not acost.any() and int(cross[3][0, 0]) == 3
         views = np.zeros((2, 4, 4, 3), np.uint8)
         host_api.mux_multiview([views[0], views[1]], 80.0, 4, 4)  # round(N / tan(angle) / 3) == 0: `ty % 0` in d_mux_multiview.cu:55
         assert b"y_interval" in lib.stm_last_error()
@@ -496,6 +500,7 @@ def test_error_mode_records_instead_of_exiting(gpu_ready, stm):
         host_api.dc_wta(np.zeros((0, 4, 4), np.float32), 0)         # no hypotheses
         assert b"num_disp = 0" in lib.stm_last_error()
     finally:
+        lib.stm_set_agg_variant(0)
         lib.stm_set_error_mode(0)
 
 
