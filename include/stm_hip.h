@@ -77,6 +77,12 @@ void        stm_set_agg_variant(int v);
  * (d_dr_irv.cu:36 -- the bin INDEX, SURVEY A-Q17 iv); 1 = the paper's rule, (winning bin's COUNT) / S > thresh_h (Mei et al.,
  * region voting).  An addition: the reference has no such switch. */
 void        stm_set_irv_paper_ratio(int on);
+/* ci_adcensus / d_ci_adcensus (the per-stage calls; the frame calls always compute the clean costs): 0 (default) = clean
+ * clamped indexing, the canonical form (SURVEY A-Q7); 1 = reproduce the reference's shared-tile strays at d = 0 in columns
+ * 160 k (left cost) and 160 k + 159 (right cost): the census term always, the AD term when num_disp - zero_disp <= zero_disp
+ * (d_ci_adcensus.cu:57-59,117-120; d_ci_census.cu:240-246; d_ci_ad.cu:133-144).  Meaningful for num_cols % 160 == 0, the
+ * only widths for which the reference's own launch fills its tiles.  An addition: the reference has no such switch. */
+void        stm_set_ref_quirks(int on);
 
 /* ------------------------------------------------------- cost init (a1-a7) */
 /* d_ci_adcensus.h:23-25  ci_adcensus  (d_ci_adcensus.cu:188-378) */

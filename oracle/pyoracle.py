@@ -76,6 +76,16 @@ def _f32(a):
     return a, a.ctypes.data_as(f32p)
 
 
+def set_ref_quirks(on):
+    """Non-default: the reference's shared-tile strays at d = 0 (SURVEY A-Q7) in ci_adcensus; widths that are multiples of 160."""
+    lib().orc_set_ref_quirks(int(bool(on)))
+
+
+def set_irv_paper_ratio(on):
+    """Non-default: region voting accepts on count / S instead of the reference's bin index / S (SURVEY A-Q17 iv)."""
+    lib().orc_set_irv_paper_ratio(int(bool(on)))
+
+
 def num_threads():
     return int(lib().orc_num_threads())
 

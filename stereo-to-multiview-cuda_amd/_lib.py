@@ -32,6 +32,7 @@ PROTOS = {
     "stm_prof_read": ([C.c_char_p, f32p], i),
     "stm_set_agg_variant": ([i], None),
     "stm_set_irv_paper_ratio": ([i], None),
+    "stm_set_ref_quirks": ([i], None),
     "stm_ci_adcensus": ([u8p, u8p, f32pp, f32pp, f, f, i, i, i, i, i], None),
     "stm_d_ci_adcensus": ([vp, vp, vp, vp, f32pp, f32pp, vp, f, f, i, i, i, i, i], None),
     "stm_ca_cross": ([u8p, u8pp, f32pp, f32pp, f, f, i, i, i, i, i, i], None),

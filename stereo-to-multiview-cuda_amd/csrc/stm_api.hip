@@ -123,6 +123,7 @@ void core_ci(const u8 *d_img_l, const u8 *d_img_r, Vol cl, Vol cr, uint32_t *pk_
     }
     const float *lut = rho_table(ad_coeff, census_coeff);
     launch_cost_init(pk_l, pk_r, cen_l, cen_r, cl, cr, lut, lut + 768, D, zd, H, W);
+    if (ref_quirks()) launch_cost_quirks(pk_l, pk_r, cen_l, cen_r, cl, cr, lut, lut + 768, D, zd, H, W); // per-stage ci_adcensus only (stm_hip.h)
 }
 
 // aggregation H, V, V, H (d_ca_cross.cu:255-270 minus the transposes); result ends in `cost`

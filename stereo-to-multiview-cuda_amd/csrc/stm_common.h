@@ -133,6 +133,9 @@ void launch_census32_pair(const uint32_t *packed_l, uint32_t *census_l, const ui
 void launch_cost_init(const uint32_t *pk_l, const uint32_t *pk_r, const uint32_t *cen_l, const uint32_t *cen_r,
                       Vol cost_l, Vol cost_r, const float *lut_ad, const float *lut_census,
                       int D, int zd, int H, int W);
+void launch_cost_quirks(const uint32_t *pk_l, const uint32_t *pk_r, const uint32_t *cen_l, const uint32_t *cen_r, Vol cost_l,
+                        Vol cost_r, const float *lut_ad, const float *lut_census, int D, int zd, int H, int W);
+int ref_quirks(); // stm_set_ref_quirks
 // aggregation (stm_kernels_agg.hip)
 void launch_cross_arms(const uint32_t *packed, u8 *up, u8 *down, u8 *left, u8 *right,
                        float ucd, float lcd, int usd, int lsd, int H, int W);

@@ -180,4 +180,43 @@ void launch_cost_init(const uint32_t *pk_l, const uint32_t *pk_r, const uint32_t
     STM_CHECK_LAUNCH();
 }
 
+// ref_quirks (stm_set_ref_quirks, non-default; SURVEY A-Q7): the reference's live kernels read one element past their shared
+// tiles at d = 0 in two columns of every block of 160 -- the left cost of tx = 0 pairs L(x) with census_l / img_l at
+// clamp(x + 160 + zd - 2) (the last element of the LEFT tile, d_ci_census.cu:240-246 with the padding of d_ci_adcensus.cu:117-120),
+// the right cost of tx = 159 pairs R(x) with census_r / img_r at clamp(x - 158 - zd) (the first element of the right tile);
+// the AD term strays only when D - zd <= zd (d_ci_adcensus.cu:57-59, d_ci_ad.cu:133-144).  This kernel overwrites those
+// entries of plane 0 after stm_k_cost_init wrote the clean costs.  One thread per (row, block of 160, side).
+__global__ __launch_bounds__(256) void stm_k_cost_quirks(const uint32_t *__restrict__ pk_l, const uint32_t *__restrict__ pk_r,
+                                                         const uint32_t *__restrict__ cen_l, const uint32_t *__restrict__ cen_r,
+                                                         Vol cost_l, Vol cost_r, const float *__restrict__ lut_ad,
+                                                         const float *__restrict__ lut_c, int D, int zd, int H, int W, int nblk)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= H * nblk * 2) return;
+    const int side = t & 1, b = (t >> 1) % nblk, y = (t >> 1) / nblk;
+    const int x = b * 160 + (side ? 159 : 0);
+    if (x >= W) return;
+    const size_t row = (size_t)y * W;
+    const bool ad_stray = (D - zd) <= zd;
+    const uint32_t *pk_own = side ? pk_r : pk_l, *cen_own = side ? cen_r : cen_l;
+    const int xs = min(max(side ? x - 158 - zd : x + 160 + zd - 2, 0), W - 1); // the stray element, in the OWN image
+    const int xc = min(max(side ? x + zd : x - zd, 0), W - 1);                   // the clean partner at d = 0, in the other image
+    const uint32_t p_other = ad_stray ? pk_own[row + xs] : (side ? pk_l : pk_r)[row + xc];
+    const int ad = (int)__builtin_amdgcn_sad_u8(pk_own[row + x], p_other, 0u);
+    const int hd = hamdist_ref(cen_own[row + x], cen_own[row + xs]);
+    const float c = lut_ad[ad] + lut_c[hd];
+    const Vol &dst = side ? cost_r : cost_l;
+    if (dst.quad) ((float *)dst.base)[((size_t)0 * dst.plane_stride + row + x) * 4] = c; // hypothesis 0 of quad 0
+    else dst.plane(0)[row + x] = c;
+}
+
+void launch_cost_quirks(const uint32_t *pk_l, const uint32_t *pk_r, const uint32_t *cen_l, const uint32_t *cen_r, Vol cost_l,
+                        Vol cost_r, const float *lut_ad, const float *lut_census, int D, int zd, int H, int W)
+{
+    const int nblk = cdiv(W, 160), n = H * nblk * 2;
+    STM_LAUNCH(stm_k_cost_quirks, dim3(cdiv(n, 256)), dim3(256), 0, stream(), pk_l, pk_r, cen_l, cen_r, cost_l, cost_r, lut_ad,
+               lut_census, D, zd, H, W, nblk);
+    STM_CHECK_LAUNCH();
+}
+
 } // namespace stm

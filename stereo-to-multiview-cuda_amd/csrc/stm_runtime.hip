@@ -186,6 +186,8 @@ ProfScope::~ProfScope()
 
 static int g_agg_variant = 0;
 int agg_variant() { return g_agg_variant; }
+static int g_ref_quirks = 0;
+int ref_quirks() { return g_ref_quirks; }
 static int g_irv_paper_ratio = 0;
 int irv_paper_ratio() { return g_irv_paper_ratio; }
 
@@ -279,6 +281,7 @@ int stm_prof_read(const char *kernel, float *total_ms)
     if (total_ms) *total_ms = tot;
     return n;
 }
+void stm_set_ref_quirks(int on) { stm::g_ref_quirks = on ? 1 : 0; }
 void stm_set_irv_paper_ratio(int on) { stm::g_irv_paper_ratio = on ? 1 : 0; }
 void stm_set_agg_variant(int v)
 {

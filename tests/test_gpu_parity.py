@@ -874,3 +874,57 @@ def test_random_frames_and_parameters(gpu_ready, orc, c):
                             p.lsd, p.thresh_s, p.thresh_h)
     assert np.array_equal(dl.cpu().numpy(), want["disp_l"]) and np.array_equal(dr.cpu().numpy(), want["disp_r"])
     assert np.array_equal(out.cpu().numpy(), want["interlaced"])
+
+
+def test_ref_quirks_mode_of_the_per_stage_cost_init(gpu_ready, stm, orc):
+    """stm_set_ref_quirks(1): ci_adcensus reproduces the reference's shared-tile strays at d = 0 (SURVEY A-Q7) -- on the
+    reference's own pair at the size its launch geometry is valid for (640 = 4 x 160 columns, D = 32, zd = 16: census and AD
+    strays) and with D - zd > zd (census strays only).  Non-default; oracle mode orc.set_ref_quirks."""
+    import os
+    from conftest import GOLDEN
+    from stm_amd import bmp_io, host_api
+    L, R = bmp_io.read_bmp(os.path.join(GOLDEN, "bud_2.bmp")), bmp_io.read_bmp(os.path.join(GOLDEN, "bud_3.bmp"))
+    lib = stm.lib()
+    for (rows, D, zd) in ((slice(0, 384), 32, 16), (slice(100, 140), 64, 10)):
+        Lc, Rc = np.ascontiguousarray(L[rows]), np.ascontiguousarray(R[rows])
+        clean = host_api.ci_adcensus(Lc, Rc, 10.0, 30.0, D, zd)
+        lib.stm_set_ref_quirks(1)
+        orc.set_ref_quirks(1)
+        try:
+            got = host_api.ci_adcensus(Lc, Rc, 10.0, 30.0, D, zd)
+            want = orc.ci_adcensus(Lc, Rc, 10.0, 30.0, D, zd)
+        finally:
+            lib.stm_set_ref_quirks(0)
+            orc.set_ref_quirks(0)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        assert not np.array_equal(got[0][0], clean[0][0]) and np.array_equal(got[0][1:], clean[0][1:])
+
+
+def test_paper_ratio_mode_of_region_voting(gpu_ready, stm, orc):
+    """stm_set_irv_paper_ratio(1): dr_irv accepts on count / S instead of the reference's bin index / S (SURVEY A-Q17 iv);
+    both rules against the oracle's, on a real crop where they differ."""
+    import os
+    from conftest import GOLDEN
+    from stm_amd import bmp_io, host_api
+    L = np.ascontiguousarray(bmp_io.read_bmp(os.path.join(GOLDEN, "bud_2.bmp"))[120:248, 200:456])
+    R = np.ascontiguousarray(bmp_io.read_bmp(os.path.join(GOLDEN, "bud_3.bmp"))[120:248, 200:456])
+    D, zd, usd, lsd = 32, 16, 17, 8
+    cl, cr = host_api.ci_adcensus(L, R, 10.0, 30.0, D, zd)
+    cross_l, al = host_api.ca_cross(L, cl, 6.0, 20.0, usd, lsd)
+    cross_r, ar = host_api.ca_cross(R, cr, 6.0, 20.0, usd, lsd)
+    dl, dr = host_api.dc_wta(al, zd), host_api.dc_wta(ar, zd)
+    ol, _ = host_api.dr_dcc(dl, dr)
+    lib = stm.lib()
+    res = {}
+    for mode in (0, 1):
+        lib.stm_set_irv_paper_ratio(mode)
+        orc.set_irv_paper_ratio(mode)
+        try:
+            g = host_api.dr_irv(dl, ol, cross_l, 20, 0.4, D, zd, usd, 5)
+            w = orc.dr_irv(dl, ol, cross_l, 20, 0.4, D, zd, usd, 5, device_flavour=False)
+        finally:
+            lib.stm_set_irv_paper_ratio(0)
+            orc.set_irv_paper_ratio(0)
+        assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1])
+        res[mode] = g
+    assert not np.array_equal(res[0][1], res[1][1])  # the two rules accept different pixels here

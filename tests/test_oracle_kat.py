@@ -263,3 +263,105 @@ def test_c1_full_size_golden_regression(orc):
     assert np.array_equal(fr["interlaced"], g["frame_mux"])
     mode, share, outl = g["stats"]
     assert mode == -6 and 0.45 < share < 0.58 and 0.10 < outl < 0.20
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Non-default oracle modes: ref_quirks (A-Q7) and paper_ratio (A-Q17 iv)
+
+def _ref_tile_partner(kind, D, zd, W, x, d, side):
+    """Which (image, column) the reference's live cost kernels read for pixel x, hypothesis d: their shared-tile index
+    arithmetic replayed on a tile of (image, column) tags.  kind 'census': ci_census_kernel_6 (d_ci_census.cu:221-246) with
+    the padding of d_ci_adcensus.cu:117-120; kind 'ad': ci_ad_kernel_5 (d_ci_ad.cu:100-144) with d_ci_adcensus.cu:57-59.
+    Both tiles of a block sit back to back in ONE dynamic shared array, so an index one past a tile lands in the other."""
+    bw = 160
+    gx0, tx = x - x % bw, x % bw
+    cl = lambda g: min(max(g, 0), W - 1)
+    if kind == "census":
+        pad_l, pad_r = zd - 1, D - zd
+        cols = bw + D - 1
+        sm = [("L", cl(gx0 - pad_r + j)) for j in range(cols)] + [("R", cl(gx0 - pad_l + j)) for j in range(cols)]
+        idx = cols + tx + pad_l + (d - zd) if side == "l" else tx + pad_r - (d - zd)
+    else:
+        P = (D - zd) if (D - zd) > zd else zd - 1
+        cols = bw + 2 * P
+        sm = [("L", cl(gx0 - P + j)) for j in range(cols)] + [("R", cl(gx0 - P + j)) for j in range(cols)]
+        idx = cols + tx + P + (d - zd) if side == "l" else tx + P - (d - zd)
+    assert 0 <= idx < len(sm), "the read leaves the dynamic shared allocation: undefined, not a quirk"
+    return sm[idx]
+
+
+@pytest.mark.parametrize("D,zd", [(32, 16), (32, 15), (32, 20), (64, 32), (64, 10)])
+def test_ref_quirk_index_claims(D, zd):
+    """SURVEY Appendix A, last paragraph: with block width 160 the census kernel strays at (tx = 0, d = 0) on the left cost
+    and (tx = 159, d = 0) on the right cost for every (D, zd); the AD kernel exactly when D - zd <= zd; every other read is
+    the clean clamped partner."""
+    W = 320
+    cl = lambda g: min(max(g, 0), W - 1)
+    for kind in ("census", "ad"):
+        strays = set()
+        for x in range(W):
+            for d in range(D):
+                if _ref_tile_partner(kind, D, zd, W, x, d, "l") != ("R", cl(x + d - zd)):
+                    strays.add(("l", x % 160, d))
+                    assert _ref_tile_partner(kind, D, zd, W, x, d, "l") == ("L", cl(x + 160 + zd - 2))
+                if _ref_tile_partner(kind, D, zd, W, x, d, "r") != ("L", cl(x - (d - zd))):
+                    strays.add(("r", x % 160, d))
+                    assert _ref_tile_partner(kind, D, zd, W, x, d, "r") == ("R", cl(x - 158 - zd))
+        want = {("l", 0, 0), ("r", 159, 0)} if (kind == "census" or D - zd <= zd) else set()
+        assert strays == want, (kind, D, zd, strays)
+
+
+@pytest.mark.parametrize("D,zd", [(32, 16), (64, 10)])
+def test_ref_quirks_mode_of_the_oracle(orc, D, zd):
+    """orc.set_ref_quirks(1): plane 0 differs from the clean volume in columns 160 k (left) / 160 k + 159 (right) only, and
+    there it is the cost of the pair the reference's tile arithmetic reads (replayed above), rebuilt from the oracle's own
+    grey / census / Hamming / rho pieces."""
+    H, W = 3, 320
+    L, R = rand_pair(H, W, seed=5)
+    clean_l, clean_r = orc.ci_adcensus(L, R, 10.0, 30.0, D, zd)
+    orc.set_ref_quirks(1)
+    try:
+        q_l, q_r = orc.ci_adcensus(L, R, 10.0, 30.0, D, zd)
+    finally:
+        orc.set_ref_quirks(0)
+    assert np.array_equal(q_l[1:], clean_l[1:]) and np.array_equal(q_r[1:], clean_r[1:])
+    cols_l, cols_r = np.arange(0, W, 160), np.arange(159, W, 160)
+    keep_l, keep_r = np.ones(W, bool), np.ones(W, bool)
+    keep_l[cols_l] = False
+    keep_r[cols_r] = False
+    assert np.array_equal(q_l[0][:, keep_l], clean_l[0][:, keep_l]) and np.array_equal(q_r[0][:, keep_r], clean_r[0][:, keep_r])
+    lut_ad, lut_c = orc.rho_luts(10.0, 30.0)
+    cen = {"L": orc.census(orc.grey(L)), "R": orc.census(orc.grey(R))}
+    img = {"L": L.astype(np.int32), "R": R.astype(np.int32)}
+    for side, own, vol, cols in (("l", "L", q_l, cols_l), ("r", "R", q_r, cols_r)):
+        for y in range(H):
+            for x in cols:
+                ci, cx = _ref_tile_partner("census", D, zd, W, int(x), 0, side)
+                ai, ax = _ref_tile_partner("ad", D, zd, W, int(x), 0, side)
+                sad = int(np.abs(img[own][y, x] - img[ai][y, ax]).sum())
+                ham = orc.hamdist64(int(cen[own][y, x]), int(cen[ci][y, cx]))
+                assert vol[0, y, x] == np.float32(lut_ad[sad] + lut_c[ham]), (side, y, x)
+    assert not np.array_equal(q_l[0], clean_l[0])  # the mode does change something on a random pair
+
+
+def test_paper_ratio_mode_of_the_oracle(orc):
+    """orc.set_irv_paper_ratio(1): region voting accepts on (winning count) / S instead of (winning bin index) / S
+    (d_dr_irv.cu:36, SURVEY A-Q17 iv).  A 9x9 flat patch with one outlier in the middle: 80 votes for bin 3 + zd.  With
+    zd = 0 and thresh_h = 0.4 the reference's rule sees 3 / 80 < 0.4 (reject), the paper's 80 / 80 > 0.4 (accept)."""
+    H = W = 9
+    disp = np.full((H, W), 3.0, np.float32)
+    disp[4, 4] = 7.0
+    outl = np.zeros((H, W), np.uint8)
+    outl[4, 4] = 1
+    cross = np.zeros((4, H, W), np.uint8)
+    for y in range(H):
+        for x in range(W):
+            cross[:, y, x] = (y, H - 1 - y, x, W - 1 - x)
+    d0, o0 = orc.dr_irv(disp, outl, cross, 20, 0.4, 16, 0, 8, 1)
+    assert d0[4, 4] == 7.0 and o0[4, 4] == 1
+    orc.set_irv_paper_ratio(1)
+    try:
+        d1, o1 = orc.dr_irv(disp, outl, cross, 20, 0.4, 16, 0, 8, 1)
+    finally:
+        orc.set_irv_paper_ratio(0)
+    assert d1[4, 4] == 3.0 and o1[4, 4] == 0
