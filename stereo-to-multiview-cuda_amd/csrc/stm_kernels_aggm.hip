@@ -804,7 +804,8 @@ struct V12Sweep { // a tile's sweep whose first quad is already on its way (issu
 #define STM_V12_ARRIVED(Q) __builtin_amdgcn_sched_barrier(0); asm volatile("" : : "v"(Q.c), "s"(Q.m0), "s"(Q.m1), "s"(Q.m2), "s"(Q.m3) : "memory");
 #define STM_V12_MFMA(Q)                                                                                            \
     {                                                                                                              \
-        const float a0 = STM_MASKF(Q.m0), a1 = STM_MASKF(Q.m1), a2 = STM_MASKF(Q.m2), a3 = STM_MASKF(Q.m3);        \
+        float a0 = STM_MASKF(Q.m0), a1 = STM_MASKF(Q.m1), a2 = STM_MASKF(Q.m2), a3 = STM_MASKF(Q.m3);              \
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)); /* all four selects in front of the MFMAs: no hazard padding between them */ \
         acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a0, Q.c.x, acc, 0, 0, 0);                                       \
         acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a1, Q.c.y, acc, 0, 0, 0);                                       \
         acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a2, Q.c.z, acc, 0, 0, 0);                                       \
