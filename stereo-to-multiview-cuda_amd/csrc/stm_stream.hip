@@ -3,8 +3,12 @@
 // The reference's video loop (video_io.cpp:144-165) calls adcensus_stm once per decoded frame; every call
 // uploads the frame, computes, downloads three results and only then returns, so PCIe transfers and compute
 // never overlap.  This front end keeps the same per-frame contract (one SBS frame in; disp_l, disp_r and the
-// interlaced frame out, in submission order) but runs three HIP streams over double-buffered pinned / device
-// buffers: while frame k computes, frame k+1 is uploading and frame k-1 is downloading.
+// interlaced frame out, in submission order) but runs an upload stream, a download stream and one COMPUTE stream +
+// private workspace per buffer slot over double-buffered pinned / device buffers: while frame k computes, frame k+1 is
+// uploading and frame k-1 is downloading, and (round 3) the two frames in flight also overlap ON the GPU: the
+// latency-bound tail of frame k (region voting, filters, view synthesis) shares the chip with the issue-bound aggregation
+// of frame k+1 (bench.py's rate_two_in_flight measures that overlap for device-resident frames).  STM_STREAM_OVERLAP=0: one
+// compute stream and workspace for both slots, as in round 2.
 #include "stm_common.h"
 #include "../../include/stm_hip.h"
 
@@ -18,6 +22,8 @@ struct Slot {
     float *d_dl = nullptr, *d_dr = nullptr, *h_dl = nullptr, *h_dr = nullptr;
     hipEvent_t ev_in, ev_done, ev_out;
     bool busy = false;
+    hipStream_t s_compute = nullptr; // this slot's compute stream and private workspace (shared by both slots when overlap is off)
+    void *ws = nullptr;              // private: the addresses baked into the slot's graph stay valid
     // the slot's frame pipeline as a captured graph: a frame is ~30 launches with fixed arguments (the slot's buffers,
     // the stream's private workspace), replayed with one hipGraphLaunch
     hipGraphExec_t gexec = nullptr;
@@ -31,8 +37,8 @@ struct FrameStream {
     float angle, ad, ce, ucd, lcd, thresh_h;
     size_t in_sz, out_sz, hw;
     int dev = 0; // the device the stream was created on: submit / collect switch to it (and back) if the caller's differs
-    hipStream_t s_in, s_compute, s_out;
-    void *ws = nullptr;  // private workspace: addresses baked into the graphs stay valid
+    hipStream_t s_in, s_out;
+    bool overlap = true; // two frames in flight on the GPU (a compute stream + workspace per slot)
     bool use_graph = true;
     Slot slot[2];
     long submitted = 0, collected = 0;
@@ -55,12 +61,20 @@ void *stm_stream_create(int num_rows, int num_cols_sbs, int num_cols, int num_ro
     f->hw = (size_t)num_rows * num_cols;
     STM_CHECK(hipGetDevice(&f->dev));
     STM_CHECK(hipStreamCreateWithFlags(&f->s_in, hipStreamNonBlocking));
-    STM_CHECK(hipStreamCreateWithFlags(&f->s_compute, hipStreamNonBlocking));
     STM_CHECK(hipStreamCreateWithFlags(&f->s_out, hipStreamNonBlocking));
-    f->ws = stm::ws_private_create();
     const char *g = getenv("STM_STREAM_GRAPH"); // STM_STREAM_GRAPH=0: always launch kernel by kernel
     f->use_graph = !(g && g[0] == '0');
-    for (Slot &s : f->slot) {
+    const char *o = getenv("STM_STREAM_OVERLAP"); // STM_STREAM_OVERLAP=0: one compute stream + workspace for both slots
+    f->overlap = !(o && o[0] == '0');
+    for (int i = 0; i < 2; ++i) {
+        Slot &s = f->slot[i];
+        if (i == 0 || f->overlap) {
+            STM_CHECK(hipStreamCreateWithFlags(&s.s_compute, hipStreamNonBlocking));
+            s.ws = stm::ws_private_create();
+        } else {
+            s.s_compute = f->slot[0].s_compute;
+            s.ws = f->slot[0].ws;
+        }
         STM_CHECK(hipHostMalloc((void **)&s.h_in, f->in_sz, hipHostMallocDefault));
         STM_CHECK(hipHostMalloc((void **)&s.h_out, f->out_sz, hipHostMallocDefault));
         STM_CHECK(hipHostMalloc((void **)&s.h_dl, f->hw * 4, hipHostMallocDefault));
@@ -69,7 +83,7 @@ void *stm_stream_create(int num_rows, int num_cols_sbs, int num_cols, int num_ro
         STM_CHECK(hipMalloc((void **)&s.d_out, f->out_sz));
         STM_CHECK(hipMalloc((void **)&s.d_dl, f->hw * 4));
         STM_CHECK(hipMalloc((void **)&s.d_dr, f->hw * 4));
-        STM_CHECK(hipMemsetAsync(s.d_out, 0, f->out_sz, f->s_compute)); // ordered before the first frame's writes
+        STM_CHECK(hipMemsetAsync(s.d_out, 0, f->out_sz, s.s_compute)); // ordered before the first frame's writes
         STM_CHECK(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
         STM_CHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
         STM_CHECK(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
@@ -93,10 +107,10 @@ long stm_stream_submit(void *h, const unsigned char *img_sbs)
     if (img_sbs && img_sbs != s.h_in) memcpy(s.h_in, img_sbs, f->in_sz);
     STM_CHECK(hipMemcpyAsync(s.d_in, s.h_in, f->in_sz, hipMemcpyHostToDevice, f->s_in));
     STM_CHECK(hipEventRecord(s.ev_in, f->s_in));
-    STM_CHECK(hipStreamWaitEvent(f->s_compute, s.ev_in, 0));
+    STM_CHECK(hipStreamWaitEvent(s.s_compute, s.ev_in, 0));
     void *prev = stm_get_stream();
-    stm_set_stream(f->s_compute);
-    stm::ws_private_bind(f->ws);
+    stm_set_stream(s.s_compute);
+    stm::ws_private_bind(s.ws);
     auto pipeline = [&]() {
         stm::ApiNest nest; // a failed upload above must survive the nested call's argument screen
         stm_d_adcensus_stm(s.d_in, s.d_dl, s.d_dr, s.d_out, f->H, f->Wsbs, f->W, f->Hout, f->Wout, f->E, f->N, f->angle, f->D,
@@ -110,15 +124,15 @@ long stm_stream_submit(void *h, const unsigned char *img_sbs)
         s.gexec = nullptr;
     }
     if (s.gexec) {
-        STM_CHECK(hipGraphLaunch(s.gexec, f->s_compute));
+        STM_CHECK(hipGraphLaunch(s.gexec, s.s_compute));
     } else if (f->use_graph && s.eager_runs >= 1 && !stm::prof_enabled()) {
         // the slot's first frame ran eagerly (it sized the workspace, built the lookup tables, raised the LDS limits), so
         // nothing in here allocates or synchronises: capture this frame's launches, then run the capture
         hipGraph_t graph = nullptr;
-        STM_CHECK(hipStreamBeginCapture(f->s_compute, hipStreamCaptureModeThreadLocal));
+        STM_CHECK(hipStreamBeginCapture(s.s_compute, hipStreamCaptureModeThreadLocal));
         pipeline();
         const bool capture_failed = stm::failed(); // error mode 1: something inside the capture recorded an error
-        STM_CHECK(hipStreamEndCapture(f->s_compute, &graph)); // always leave capture mode
+        STM_CHECK(hipStreamEndCapture(s.s_compute, &graph)); // always leave capture mode
         if (capture_failed || !graph) {
             if (graph) STM_CHECK(hipGraphDestroy(graph));
             f->use_graph = false; // stay eager from now on
@@ -130,14 +144,14 @@ long stm_stream_submit(void *h, const unsigned char *img_sbs)
         STM_CHECK(hipGraphInstantiate(&s.gexec, graph, nullptr, nullptr, 0));
         STM_CHECK(hipGraphDestroy(graph));
         stm::ws_identity(&s.g_ws_base, &s.g_ws_cap);
-        STM_CHECK(hipGraphLaunch(s.gexec, f->s_compute));
+        STM_CHECK(hipGraphLaunch(s.gexec, s.s_compute));
     } else {
         pipeline();
         ++s.eager_runs;
     }
     stm::ws_private_bind(nullptr);
     stm_set_stream(prev);
-    STM_CHECK(hipEventRecord(s.ev_done, f->s_compute));
+    STM_CHECK(hipEventRecord(s.ev_done, s.s_compute));
     STM_CHECK(hipStreamWaitEvent(f->s_out, s.ev_done, 0));
     STM_CHECK(hipMemcpyAsync(s.h_dl, s.d_dl, f->hw * 4, hipMemcpyDeviceToHost, f->s_out));
     STM_CHECK(hipMemcpyAsync(s.h_dr, s.d_dr, f->hw * 4, hipMemcpyDeviceToHost, f->s_out));
@@ -194,7 +208,7 @@ void stm_stream_destroy(void *h)
     FrameStream *f = (FrameStream *)h;
     if (!f) return;
     STM_CHECK(hipStreamSynchronize(f->s_in));
-    STM_CHECK(hipStreamSynchronize(f->s_compute));
+    for (Slot &s : f->slot) STM_CHECK(hipStreamSynchronize(s.s_compute));
     STM_CHECK(hipStreamSynchronize(f->s_out));
     for (Slot &s : f->slot) {
         STM_CHECK(hipHostFree(s.h_in)); STM_CHECK(hipHostFree(s.h_out)); STM_CHECK(hipHostFree(s.h_dl)); STM_CHECK(hipHostFree(s.h_dr));
@@ -202,8 +216,13 @@ void stm_stream_destroy(void *h)
         STM_CHECK(hipEventDestroy(s.ev_in)); STM_CHECK(hipEventDestroy(s.ev_done)); STM_CHECK(hipEventDestroy(s.ev_out));
         if (s.gexec) STM_CHECK(hipGraphExecDestroy(s.gexec));
     }
-    stm::ws_private_destroy(f->ws);
-    STM_CHECK(hipStreamDestroy(f->s_in)); STM_CHECK(hipStreamDestroy(f->s_compute)); STM_CHECK(hipStreamDestroy(f->s_out));
+    stm::ws_private_destroy(f->slot[0].ws);
+    STM_CHECK(hipStreamDestroy(f->slot[0].s_compute));
+    if (f->overlap) {
+        stm::ws_private_destroy(f->slot[1].ws);
+        STM_CHECK(hipStreamDestroy(f->slot[1].s_compute));
+    }
+    STM_CHECK(hipStreamDestroy(f->s_in)); STM_CHECK(hipStreamDestroy(f->s_out));
     delete f;
 }
 
