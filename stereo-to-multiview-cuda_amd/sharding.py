@@ -116,6 +116,8 @@ class FrameBatchPipeline:
         return scatter_frames(self.inbuf[k & 1], b, self.B, self.rank, self.world, self.src, async_op=True)
 
     def run(self, batches, n_batches, run_frame, on_result=None):
+        if n_batches <= 0:
+            return
         pending_in = self._scatter(0, batches)
         pending_out = [None, None]  # per buffer: list of (name, work, finish) of the gather still reading it
 
