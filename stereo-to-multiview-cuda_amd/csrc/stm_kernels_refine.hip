@@ -118,6 +118,8 @@ struct IrvArgs {
     // Two planes: iteration `it` reads plane it & 1 (the state all its votes see, as the reference's separate vote
     // and apply kernels guarantee) and writes the pixels it accepts into the other plane.
     uint16_t *code[2][2];
+    // rel[v][y][x], x in [0, W]: reliable (non-outlier) pixels of row y in columns < x, on the state BEFORE the first iteration
+    const uint16_t *rel[2];
 };
 constexpr uint32_t IV_ACCEPTED = 0x80000000u; // list entry: pixel accepted in the previous iteration
 constexpr uint32_t IV_DEAD = 0xFFFFFFFFu;     // list entry: nothing left to do
@@ -140,6 +142,31 @@ __global__ __launch_bounds__(256) void stm_k_irv_clear(int *__restrict__ words, 
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) words[i] = 0;
+}
+
+// Row prefix counts of the reliable pixels (outlier == 0) before the first iteration: rel[y][x] = how many of the pixels
+// (y, 0 .. x - 1) are reliable.  One wave per image row.  The vote kernel uses them to retire, in one step per outlier, every
+// outlier that can never be accepted (see there).
+__global__ __launch_bounds__(64) void stm_k_irv_rowprefix(const u8 *__restrict__ outl0, const u8 *__restrict__ outl1, uint16_t *__restrict__ rel0,
+                                                          uint16_t *__restrict__ rel1, int H, int W)
+{
+    const u8 *__restrict__ outl = blockIdx.y ? outl1 : outl0;
+    uint16_t *__restrict__ rel = (blockIdx.y ? rel1 : rel0) + (size_t)blockIdx.x * (W + 1);
+    const int lane = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * W;
+    int carry = 0;
+    if (lane == 0) rel[0] = 0;
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + lane;
+        int incl = (x < W && outl[row + x] == 0) ? 1 : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (x < W) rel[x + 1] = (uint16_t)(carry + incl);
+        carry += __builtin_amdgcn_readlane(incl, 63);
+    }
 }
 
 // four pixels per thread (one dword of the u8 outlier map), 4096 pixels per block; the block's outliers are
@@ -274,6 +301,7 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
     const uint32_t sub_addr = (uint32_t)((wave * nslot * 4 + (lane & 3)) * 4); // LDS byte address of copy lane % 4 of slot 0
     const uint32_t lane2 = 2u * lane;
     const int n = min(a.counts[v][0], H * W); // never past the list (capacity H W), whatever the counter holds
+    const bool prune = it == 0 && !paper_ratio && a.rel[v] != nullptr; // with the paper's rule the numerator is a count: no such bound
     const int stride = gridDim.x * IV_WAVES;
     int i = blockIdx.x * IV_WAVES + wave;
     uint32_t entry_next = i < n ? list[i] : IV_DEAD;
@@ -306,11 +334,34 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
             if (lane < nt) d = dirty[(ty0 + lane / nx) * tiles_x + tx0 + lane % nx];
             if (__ballot(d != 0) == 0) continue; // same region contents as last time -> same vote -> rejected again
         }
+        const int nrows = cu + cd + 1; // rows gy-cu .. gy+cd inclusive (SURVEY A-Q17 iii)
+        const int y_top = gy - cu;
+        if (prune) {
+            // The reference accepts on (winning bin INDEX + ... ) / S > thresh_h (d_dr_irv.cu:36, SURVEY A-Q17 iv), and the
+            // numerator can never exceed nmax = max(nb - 1, (int)own + zd): once S, the number of reliable pixels of the region,
+            // has grown past nmax / thresh_h the outlier can NEVER be accepted, whatever its votes -- and S only grows (accepted
+            // pixels become reliable, nothing becomes unreliable).  S on the state before the first iteration is a lower bound
+            // for every later S, and costs ONE step per 64 region rows: lane = row, two loads from the row prefix counts.
+            // Float division is monotone in both arguments, so the test below implies the reference's test fails, exactly.
+            int cnt = 0;
+            for (int jb = 0; jb < nrows; jb += 64)
+                if (jb + lane < nrows) {
+                    const int yy = y_top + jb + lane, q = yy * W + gx;
+                    const int cl = min((int)aL[q], gx);
+                    const int w = max(min(cl + (int)aR[q] + 1, W - (gx - cl)), 0);
+                    const uint16_t *pr = a.rel[v] + (size_t)yy * (W + 1) + (gx - cl);
+                    cnt += (int)pr[w] - (int)pr[0];
+                }
+            const int s_lb = (int)wave_sum_u32((uint32_t)cnt);
+            const int nmax = max(nb - 1, (int)own + zd);
+            if (s_lb > 0 && !((float)nmax / (float)s_lb > thresh_h)) {
+                if (lane == 0) list[i] = IV_DEAD; // retired for every later iteration too
+                continue;
+            }
+        }
         for (int sl = lane; sl <= nb; sl += 64) *(uint4 *)(hist + sl * 4) = make_uint4(0, 0, 0, 0); // the per-lane slots are never read
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int nrows = cu + cd + 1; // rows gy-cu .. gy+cd inclusive (SURVEY A-Q17 iii)
-        const int y_top = gy - cu;
         for (int jb = 0; jb < nrows; jb += 64) {
             // lane r of the chunk: row y_top + jb + r; segment [gx - armL, gx + armR] clamped into the image row (a no-op for
             // consistent arms): byte offset of its first pixel in the code plane, and its width (0 past the region)
@@ -414,6 +465,13 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
         a.code[v][1] = Workspace::get<uint16_t>(HW + 64);
     }
     if (nviews == 1) { a.list[1] = a.list[0]; a.code[1][0] = a.code[0][0]; a.code[1][1] = a.code[0][1]; }
+    // the row prefix counts of the reliable pixels: only worth building when the vote kernel can use them
+    const bool prune = device_flavour ? !irv_paper_ratio() && W <= 65535 : false; // the host flavour votes once: nothing later to save
+    uint16_t *rel[2] = {nullptr, nullptr};
+    if (prune)
+        for (int v = 0; v < nviews; ++v) rel[v] = Workspace::get<uint16_t>((size_t)H * (W + 1));
+    a.rel[0] = rel[0];
+    a.rel[1] = nviews == 2 ? rel[1] : rel[0];
     if (rounds == 0) return; // nothing observable happens (a host-flavour vote without an apply only fills scratch)
     if (HW >= IV_ACCEPTED) {
         fail("dr_irv: more than 2^31 - 1 pixels", "num_rows * num_cols", __FILE__, __LINE__);
@@ -425,6 +483,10 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
     STM_LAUNCH(stm_k_irv_compact, dim3((unsigned)((HW + 4 * IC_T - 1) / (4 * IC_T)), nviews), dim3(IC_T), 0, stream(), a, (uint32_t)HW, zd,
                        nb);
     STM_CHECK_LAUNCH();
+    if (prune) {
+        STM_LAUNCH(stm_k_irv_rowprefix, dim3(H, nviews), dim3(64), 0, stream(), a.outl[0], a.outl[1], rel[0], nviews == 2 ? rel[1] : rel[0], H, W);
+        STM_CHECK_LAUNCH();
+    }
     const size_t smem = (size_t)(nb + 1 + 64) * 16 * IV_WAVES; // per wave: four copies of (other, nb bins), one slot per lane
     // Several times more waves than the chip holds (1080p: 8100 blocks of 2 waves per view for 8192 wave slots): the waves walk
     // the list with a fixed stride and outliers differ a lot in work, so freed slots must be refilled by the dispatcher --
