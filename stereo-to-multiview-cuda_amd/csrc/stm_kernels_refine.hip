@@ -118,8 +118,9 @@ struct IrvArgs {
     // Two planes: iteration `it` reads plane it & 1 (the state all its votes see, as the reference's separate vote
     // and apply kernels guarantee) and writes the pixels it accepts into the other plane.
     uint16_t *code[2][2];
-    // rel[v][y][x], x in [0, W]: reliable (non-outlier) pixels of row y in columns < x, on the state BEFORE the first iteration
-    const uint16_t *rel[2];
+    // vp[v][y][x], y in [0, H]: reliable (non-outlier) pixels, on the state BEFORE the first iteration, in the row segments of the
+    // pixels (0 .. y - 1, x) -- a vertical prefix sum, so that the reliable pixels of a whole cross region are one subtraction
+    const uint32_t *vp[2];
 };
 constexpr uint32_t IV_ACCEPTED = 0x80000000u; // list entry: pixel accepted in the previous iteration
 constexpr uint32_t IV_DEAD = 0xFFFFFFFFu;     // list entry: nothing left to do
@@ -144,36 +145,111 @@ __global__ __launch_bounds__(256) void stm_k_irv_clear(int *__restrict__ words, 
     if (i < n) words[i] = 0;
 }
 
-// Row prefix counts of the reliable pixels (outlier == 0) before the first iteration: rel[y][x] = how many of the pixels
-// (y, 0 .. x - 1) are reliable.  One wave per image row.  The vote kernel uses them to retire, in one step per outlier, every
-// outlier that can never be accepted (see there).
-__global__ __launch_bounds__(64) void stm_k_irv_rowprefix(const u8 *__restrict__ outl0, const u8 *__restrict__ outl1, uint16_t *__restrict__ rel0,
-                                                          uint16_t *__restrict__ rel1, int H, int W)
+// Pruning before the first iteration.  The reference accepts an outlier on (winning bin INDEX) / S > thresh_h (d_dr_irv.cu:36,
+// SURVEY A-Q17 iv), S = the reliable pixels of its cross region.  The numerator never exceeds nmax = max(nb - 1, (int)own + zd),
+// and S only grows from iteration to iteration (accepted pixels become reliable, nothing becomes unreliable): an outlier whose
+// region ALREADY holds S0 reliable pixels with nmax / S0 <= thresh_h can never be accepted, whatever its votes, in any
+// iteration (float division is monotone in both arguments, so the reference's test fails exactly when this one says so).  On a
+// 1080p frame that is most outliers: regions of several hundred pixels against nmax / thresh_h = 160.  S0 of every pixel's
+// region costs two image-sized passes:
+//   stm_k_irv_rowcount:  cnt[y][x] = reliable pixels of row y inside the row segment of pixel (y, x)  (row prefix sums in LDS);
+//   stm_k_irv_colprefix: vp[y][x]  = cnt[0][x] + .. + cnt[y - 1][x];  S0(y, x) = vp[y + armD + 1][x] - vp[y - armU][x].
+// The compaction kernel then lists only the outliers that can still be accepted.
+__global__ __launch_bounds__(64) void stm_k_irv_rowcount(IrvArgs a, uint16_t *__restrict__ cnt0, uint16_t *__restrict__ cnt1, int H, int W)
 {
-    const u8 *__restrict__ outl = blockIdx.y ? outl1 : outl0;
-    uint16_t *__restrict__ rel = (blockIdx.y ? rel1 : rel0) + (size_t)blockIdx.x * (W + 1);
-    const int lane = threadIdx.x;
-    const size_t row = (size_t)blockIdx.x * W;
+    extern __shared__ uint32_t rp[]; // rp[x] = reliable pixels of this row in columns < x, x in [0, W]
+    const int v = blockIdx.y, y = blockIdx.x, lane = threadIdx.x;
+    const u8 *__restrict__ outl = a.outl[v];
+    const u8 *__restrict__ aL = a.aL[v], *__restrict__ aR = a.aR[v];
+    uint16_t *__restrict__ cnt = (v ? cnt1 : cnt0) + (size_t)y * W;
+    const size_t row = (size_t)y * W;
     int carry = 0;
-    if (lane == 0) rel[0] = 0;
-    for (int x0 = 0; x0 < W; x0 += 64) {
-        const int x = x0 + lane;
-        int incl = (x < W && outl[row + x] == 0) ? 1 : 0;
+    if (lane == 0) rp[0] = 0;
+    for (int x0 = 0; x0 < W; x0 += 256) { // four chunks of 64 per trip: their loads are in flight together
+        u8 o[4];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
+        for (int k = 0; k < 4; ++k) o[k] = outl[row + min(x0 + 64 * k + lane, W - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { // prefix inside a chunk = population count of the ballot below the lane (v_mbcnt)
+            const int x = x0 + 64 * k + lane;
+            const bool r = x < W && o[k] == 0;
+            const unsigned long long m = __ballot(r);
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (x < W) rp[x + 1] = (uint32_t)(carry + below + (r ? 1 : 0));
+            carry += __popcll(m);
         }
-        if (x < W) rel[x + 1] = (uint16_t)(carry + incl);
-        carry += __builtin_amdgcn_readlane(incl, 63);
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int x0 = 0; x0 < W; x0 += 256) { // the row segment of the vote kernel: [x - armL, x + armR] clamped into the row
+        int al[4], ar[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = min(x0 + 64 * k + lane, W - 1);
+            al[k] = aL[row + x];
+            ar[k] = aR[row + x];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = x0 + 64 * k + lane;
+            if (x < W) {
+                const int cl = min(al[k], x);
+                const int w = max(min(cl + ar[k] + 1, W - (x - cl)), 0);
+                cnt[x] = (uint16_t)(rp[x - cl + w] - rp[x - cl]);
+            }
+        }
+    }
+}
+
+constexpr int ICP_SEG = 16; // row segments per column block
+__global__ __launch_bounds__(64 * ICP_SEG) void stm_k_irv_colprefix(const uint16_t *__restrict__ cnt0, const uint16_t *__restrict__ cnt1,
+                                                                   uint32_t *__restrict__ vp0, uint32_t *__restrict__ vp1, int H, int W)
+{
+    __shared__ uint32_t part[ICP_SEG][64];
+    const uint16_t *__restrict__ cnt = blockIdx.y ? cnt1 : cnt0;
+    uint32_t *__restrict__ vp = blockIdx.y ? vp1 : vp0;
+    const int lx = threadIdx.x & 63, seg = threadIdx.x >> 6, x = blockIdx.x * 64 + lx;
+    const int rs = (H + ICP_SEG - 1) / ICP_SEG, y0 = seg * rs, y1 = min(H, y0 + rs);
+    uint32_t sum = 0;
+    if (x < W) {
+        int y = y0;
+        for (; y + 8 <= y1; y += 8) { // eight loads in flight
+            uint32_t t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = cnt[(size_t)(y + k) * W + x];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += t[k];
+        }
+        for (; y < y1; ++y) sum += cnt[(size_t)y * W + x];
+    }
+    part[seg][lx] = sum;
+    __syncthreads();
+    if (x >= W) return;
+    uint32_t run = 0;
+    for (int s2 = 0; s2 < seg; ++s2) run += part[s2][lx];
+    int y = y0;
+    for (; y + 8 <= y1; y += 8) {
+        uint32_t t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = cnt[(size_t)(y + k) * W + x];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            vp[(size_t)(y + k) * W + x] = run;
+            run += t[k];
+        }
+    }
+    for (; y < y1; ++y) {
+        vp[(size_t)y * W + x] = run;
+        run += cnt[(size_t)y * W + x];
+    }
+    if (y1 == H && y0 < H) vp[(size_t)H * W + x] = run; // the segment that ends the column also writes the total
 }
 
 // four pixels per thread (one dword of the u8 outlier map), 4096 pixels per block; the block's outliers are
 // appended in raster order with ONE global atomic (the counter is a single address: per-wave atomics made this
 // kernel atomic-bound)
 constexpr int IC_T = 1024;
-__global__ __launch_bounds__(IC_T) void stm_k_irv_compact(IrvArgs a, uint32_t HW, int zd, int nb)
+__global__ __launch_bounds__(IC_T) void stm_k_irv_compact(IrvArgs a, uint32_t HW, int zd, int nb, int H, int W, int usd, float thresh_h)
 {
     __shared__ int s_tot[IC_T / 64];
     __shared__ int s_base;
@@ -200,6 +276,21 @@ __global__ __launch_bounds__(IC_T) void stm_k_irv_compact(IrvArgs a, uint32_t HW
             w |= (uint32_t)o << (8 * j);
             a.code[v][0][p + j] = a.code[v][1][p + j] = irv_code(o, disp[p + j], zd, nb);
         }
+    }
+    const uint32_t *__restrict__ vp = a.vp[v];
+    if (vp != nullptr && w != 0) { // outliers that can never be accepted are not listed (see stm_k_irv_rowcount)
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j)
+            if (((w >> (8 * j)) & 0xff) && p + j < HW) {
+                const int q = (int)(p + j), gy = q / W, gx = q - gy * W;
+                int cu = a.aU[v][q], cd = a.aD[v][q];
+                if (cu > usd) cu = usd;   // the clamps of the vote kernel (d_dr_irv.cu:179-180)
+                cu = min(cu, gy);
+                cd = min(cd, H - 1 - gy);
+                const int s0 = (int)(vp[(size_t)(gy + cd + 1) * W + gx] - vp[(size_t)(gy - cu) * W + gx]);
+                const int nmax = max(nb - 1, (int)disp[q] + zd);
+                if (s0 > 0 && !((float)nmax / (float)s0 > thresh_h)) w &= ~(0xffu << (8 * j));
+            }
     }
     const int c = ((w & 0xff) != 0) + ((w & 0xff00) != 0) + ((w & 0xff0000) != 0) + ((w & 0xff000000u) != 0);
     int incl = c; // inclusive scan over the wave
@@ -301,7 +392,6 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
     const uint32_t sub_addr = (uint32_t)((wave * nslot * 4 + (lane & 3)) * 4); // LDS byte address of copy lane % 4 of slot 0
     const uint32_t lane2 = 2u * lane;
     const int n = min(a.counts[v][0], H * W); // never past the list (capacity H W), whatever the counter holds
-    const bool prune = it == 0 && !paper_ratio && a.rel[v] != nullptr; // with the paper's rule the numerator is a count: no such bound
     const int stride = gridDim.x * IV_WAVES;
     int i = blockIdx.x * IV_WAVES + wave;
     uint32_t entry_next = i < n ? list[i] : IV_DEAD;
@@ -336,29 +426,6 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
         }
         const int nrows = cu + cd + 1; // rows gy-cu .. gy+cd inclusive (SURVEY A-Q17 iii)
         const int y_top = gy - cu;
-        if (prune) {
-            // The reference accepts on (winning bin INDEX + ... ) / S > thresh_h (d_dr_irv.cu:36, SURVEY A-Q17 iv), and the
-            // numerator can never exceed nmax = max(nb - 1, (int)own + zd): once S, the number of reliable pixels of the region,
-            // has grown past nmax / thresh_h the outlier can NEVER be accepted, whatever its votes -- and S only grows (accepted
-            // pixels become reliable, nothing becomes unreliable).  S on the state before the first iteration is a lower bound
-            // for every later S, and costs ONE step per 64 region rows: lane = row, two loads from the row prefix counts.
-            // Float division is monotone in both arguments, so the test below implies the reference's test fails, exactly.
-            int cnt = 0;
-            for (int jb = 0; jb < nrows; jb += 64)
-                if (jb + lane < nrows) {
-                    const int yy = y_top + jb + lane, q = yy * W + gx;
-                    const int cl = min((int)aL[q], gx);
-                    const int w = max(min(cl + (int)aR[q] + 1, W - (gx - cl)), 0);
-                    const uint16_t *pr = a.rel[v] + (size_t)yy * (W + 1) + (gx - cl);
-                    cnt += (int)pr[w] - (int)pr[0];
-                }
-            const int s_lb = (int)wave_sum_u32((uint32_t)cnt);
-            const int nmax = max(nb - 1, (int)own + zd);
-            if (s_lb > 0 && !((float)nmax / (float)s_lb > thresh_h)) {
-                if (lane == 0) list[i] = IV_DEAD; // retired for every later iteration too
-                continue;
-            }
-        }
         for (int sl = lane; sl <= nb; sl += 64) *(uint4 *)(hist + sl * 4) = make_uint4(0, 0, 0, 0); // the per-lane slots are never read
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -465,13 +532,17 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
         a.code[v][1] = Workspace::get<uint16_t>(HW + 64);
     }
     if (nviews == 1) { a.list[1] = a.list[0]; a.code[1][0] = a.code[0][0]; a.code[1][1] = a.code[0][1]; }
-    // the row prefix counts of the reliable pixels: only worth building when the vote kernel can use them
-    const bool prune = device_flavour ? !irv_paper_ratio() && W <= 65535 : false; // the host flavour votes once: nothing later to save
-    uint16_t *rel[2] = {nullptr, nullptr};
+    // pruning tables (stm_k_irv_rowcount): not with the paper's accept rule (its numerator is a count: no such bound)
+    const bool prune = !irv_paper_ratio() && W <= 16000;
+    uint16_t *cnt[2] = {nullptr, nullptr};
+    uint32_t *vp[2] = {nullptr, nullptr};
     if (prune)
-        for (int v = 0; v < nviews; ++v) rel[v] = Workspace::get<uint16_t>((size_t)H * (W + 1));
-    a.rel[0] = rel[0];
-    a.rel[1] = nviews == 2 ? rel[1] : rel[0];
+        for (int v = 0; v < nviews; ++v) {
+            cnt[v] = Workspace::get<uint16_t>(HW);
+            vp[v] = Workspace::get<uint32_t>(HW + W);
+        }
+    a.vp[0] = vp[0];
+    a.vp[1] = nviews == 2 ? vp[1] : vp[0];
     if (rounds == 0) return; // nothing observable happens (a host-flavour vote without an apply only fills scratch)
     if (HW >= IV_ACCEPTED) {
         fail("dr_irv: more than 2^31 - 1 pixels", "num_rows * num_cols", __FILE__, __LINE__);
@@ -480,13 +551,16 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
     ProfScope p("irv");
     STM_LAUNCH(stm_k_irv_clear, dim3((unsigned)cdiv((int)nwords, 256)), dim3(256), 0, stream(), counts, (int)nwords);
     STM_CHECK_LAUNCH();
-    STM_LAUNCH(stm_k_irv_compact, dim3((unsigned)((HW + 4 * IC_T - 1) / (4 * IC_T)), nviews), dim3(IC_T), 0, stream(), a, (uint32_t)HW, zd,
-                       nb);
-    STM_CHECK_LAUNCH();
     if (prune) {
-        STM_LAUNCH(stm_k_irv_rowprefix, dim3(H, nviews), dim3(64), 0, stream(), a.outl[0], a.outl[1], rel[0], nviews == 2 ? rel[1] : rel[0], H, W);
+        STM_LAUNCH(stm_k_irv_rowcount, dim3(H, nviews), dim3(64), (size_t)(W + 1) * 4, stream(), a, cnt[0], nviews == 2 ? cnt[1] : cnt[0], H, W);
+        STM_CHECK_LAUNCH();
+        STM_LAUNCH(stm_k_irv_colprefix, dim3(cdiv(W, 64), nviews), dim3(64 * ICP_SEG), 0, stream(), cnt[0], nviews == 2 ? cnt[1] : cnt[0], vp[0],
+                   nviews == 2 ? vp[1] : vp[0], H, W);
         STM_CHECK_LAUNCH();
     }
+    STM_LAUNCH(stm_k_irv_compact, dim3((unsigned)((HW + 4 * IC_T - 1) / (4 * IC_T)), nviews), dim3(IC_T), 0, stream(), a, (uint32_t)HW, zd,
+                       nb, H, W, usd, thresh_h);
+    STM_CHECK_LAUNCH();
     const size_t smem = (size_t)(nb + 1 + 64) * 16 * IV_WAVES; // per wave: four copies of (other, nb bins), one slot per lane
     // Several times more waves than the chip holds (1080p: 8100 blocks of 2 waves per view for 8192 wave slots): the waves walk
     // the list with a fixed stride and outliers differ a lot in work, so freed slots must be refilled by the dispatcher --
