@@ -5,7 +5,7 @@ per-kernel HBM traffic summary, with the corrections MI355X_MICROARCH.md section
   * FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B/lane) on gfx950, so the
     read side is doubled for the kernels that stream the cost volume as 16-byte quads (stm_k_agg_*, calibrated on
     stm_k_agg_h: corrected read = 534.7 MB vs 534.9 MB algorithmic); WRITE_SIZE is exact for 16 B/lane stores.
-usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [commit]"""
 import collections
 import csv
 import json
@@ -22,9 +22,13 @@ def per_kernel(path, counter):
 
 def short(name):
     n = name.split("(")[0].replace("void ", "").replace("stm::", "")
-    if "stm_k_pq_h" in n:
+    if "stm_k_pq_hc" in n:
+        return "pq_h"                             # round 3: the cost-computing streaming pass
+    if "stm_k_pq_hs" in n or "stm_k_pq_h<" in n:
         args = n[n.index("<") + 1:n.index(">")].split(", ")
         return "pq_hw" if len(args) >= 2 and args[1] == "true" else "pq_h"   # <NW, WTA, ...>
+    if "vwin_table" in n:
+        return "pq_vtab"
     for k in ("pq_v12", "pq_cost"):
         if k in n:
             return k
@@ -57,8 +61,12 @@ def main():
         corr = 2.0 if (("agg_" in k and short(k) != "agg_h_cost") or "cost_init" in k or short(k) in ("pq_hw", "pq_v12") or (short(k) == "pq_h" and not fused_cost)) else 1.0
         out[short(k)] = {"kernel": k.split("(")[0], "fetch_raw_bytes": f_raw, "fetch_correction": corr,
                          "write_bytes": w, "traffic_bytes": f_raw * corr + w}
+    if len(sys.argv) > 4:
+        out["commit"] = {"commit": sys.argv[4], "note": "git commit of the build these counters were taken on"}
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     for k, v in out.items():
+        if k == "commit":
+            continue
         print("%-14s read %8.1f MB (raw %8.1f) write %8.1f MB total %8.1f MB" % (k, v["fetch_raw_bytes"] * v["fetch_correction"] / 1e6,
                                                                             v["fetch_raw_bytes"] / 1e6, v["write_bytes"] / 1e6, v["traffic_bytes"] / 1e6))
 
