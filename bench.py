@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="--gpus N > 1: frames per step (default N, one per rank); rank 0 scatters every "
                     "step's frames and gathers its outputs INSIDE the timed region, double-buffered (sharding.FrameBatchPipeline)")
     ap.add_argument("--no-batch-movement", action="store_true", help="--gpus N > 1: inputs resident on every rank before timing (the round-1/2 form)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the two-frames-in-flight and real-content legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the two-frames-in-flight and real-content legs and the window statistics behind roofline.issue (profiling passes)")
     return ap.parse_args()
 
 
@@ -254,7 +254,10 @@ def main():
         frames_per_step = B  # whole job
         my_frames = float(per_rank * args.steps)  # frames behind this rank's kernel records
         L_host, R_host = np.ascontiguousarray(sbs_host[:, :W]), np.ascontiguousarray(sbs_host[:, W:])
-        sum_h, sum_v, tab_bytes = window_stats(L_host, R_host, p, H, W)
+        if args.no_extras:  # profiling passes: no launches besides the timed pipeline (the per-kernel averages stay clean)
+            sum_h = sum_v = tab_bytes = 0
+        else:
+            sum_h, sum_v, tab_bytes = window_stats(L_host, R_host, p, H, W)
         # algorithmic bytes per launch (compulsory inputs + outputs, each buffer once).  The matrix-pipe kernels
         # serve BOTH views per launch: pq_h = first horizontal pass, computing the initial costs itself (per view four dword
         # planes -- BGRX + census of both images -- and two arm planes in, V out: SURVEY 8d's K1); pq_vtab = the vertical
@@ -284,7 +287,7 @@ def main():
                                  "achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": kern[k]["avg_ms"],
                                  "launches_per_frame": kern[k]["launches"] / my_frames, "algorithmic_bytes_per_launch": alg[k],
                                  "traffic": traffic_all.get(k, {}).get("traffic_bytes")}
-                if k in useful:
+                if k in useful and useful[k] > 0:
                     tadds = useful[k] / (kern[k]["avg_ms"] * 1e-3) / 1e12
                     per_kernel[k]["issue"] = {"useful_adds_per_launch": useful[k], "achieved_Tadds": tadds, "peak": ISSUE_PEAK_TADDS,
                                               "frac": tadds / ISSUE_PEAK_TADDS}

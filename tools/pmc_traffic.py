@@ -59,8 +59,11 @@ def main():
         # dword planes (pixels, census, arms)
         # matrix-pipe kernels: pq_h / pq_hw / pq_v12 stream the volume as 16-byte elements; pq_cost reads dword planes
         corr = 2.0 if (("agg_" in k and short(k) != "agg_h_cost") or "cost_init" in k or short(k) in ("pq_hw", "pq_v12") or (short(k) == "pq_h" and not fused_cost)) else 1.0
-        out[short(k)] = {"kernel": k.split("(")[0], "fetch_raw_bytes": f_raw, "fetch_correction": corr,
-                         "write_bytes": w, "traffic_bytes": f_raw * corr + w}
+        name = short(k)
+        if name in out:  # two kernels behind one short name (e.g. the per-stage path's passes): keep both apart
+            name = k.split("(")[0].replace("void ", "").replace("stm::", "")
+        out[name] = {"kernel": k.split("(")[0], "fetch_raw_bytes": f_raw, "fetch_correction": corr,
+                     "write_bytes": w, "traffic_bytes": f_raw * corr + w}
     if len(sys.argv) > 4:
         out["commit"] = {"commit": sys.argv[4], "note": "git commit of the build these counters were taken on"}
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
