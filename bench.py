@@ -234,7 +234,7 @@ def main():
     nbreak = min(args.steps, 20)
     timed(nbreak, 1)
     ALL_NAMES = AGG_KERNELS + ("cross_arms", "hslo_classes", "hslo_lr", "hslo_rl", "hslo_tb", "hslo_bt", "hslo_to_pq", "wta", "irv", "bilateral",
-                               "gaussian_max", "view_synth", "mux")
+                               "gaussian_max", "view_synth", "mux", "synth_mux")
 
     def read_all():
         res = {}

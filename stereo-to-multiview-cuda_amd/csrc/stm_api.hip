@@ -749,6 +749,23 @@ void frame_render(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, u8 *d_
     launch_hitmask_rows(mask_l, mask_r, d_disp_l, d_disp_r, H, W); // :165-176: dibr_occl, bleed(1) x2, occl_to_mask
     launch_gaussian_max(mask_r, blend, gauss2d_table(10, 15.0f), 10, 15.0f, H, W, true); // d_dibr_bwarp.cu:60-63, once per frame
 
+    if ((agg_variant() / 100) % 10 != 2) {
+        // views + interlacing in one pass: an output pixel synthesises exactly the samples it interlaces (stm_k_synth_mux)
+        const float yi = mux_y_interval(N, angle, elem_sz);
+        if (!(fabsf(yi) < 1.0e9f)) {
+            fail("mux_multiview: y_interval is not finite (tan(angle) == 0 or angle is not a number)", "angle", __FILE__, __LINE__);
+            return;
+        }
+        const int ymod = (int)roundf(yi);
+        if (ymod == 0) {
+            fail("mux_multiview: round(y_interval) == 0 (angle too steep)", "ymod", __FILE__, __LINE__);
+            return;
+        }
+        launch_synth_mux(img_l, img_r, d_disp_l, d_disp_r, mask_l, mask_r, blend, d_interlaced, N, yi, 1.0f / yi, ymod, H, W, Hout, Wout,
+                         elem_sz, 2);
+        return;
+    }
+    // 200: the un-fused form (every view written, then interlaced), as the reference structures it (d_io.cu:182-203)
     u8 *views_mem = Workspace::get<u8>((size_t)N * IMG);
     // views[0] = right image, views[N-1] = left image (d_io.cu:182-183)
     launch_view_synth_all(views_mem, IMG, N, img_l, img_r, d_disp_l, d_disp_r, mask_l, mask_r, blend, H, W, elem_sz); // :186-201

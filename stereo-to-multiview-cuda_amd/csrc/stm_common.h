@@ -184,6 +184,10 @@ void launch_fwarp(u8 *out, const u8 *img, const float *disp, float shift, unsign
 void launch_scale_bilinear(const u8 *in, u8 *out, int in_rows, int in_cols, int out_rows, int out_cols, int elem_sz);
 void launch_disp_scale(float *out, const float *in, int out_rows, int out_cols, int in_rows, int in_cols, float disp_scale);
 void launch_view_table(u8 **tab, u8 *first, u8 *last, u8 *mem, size_t stride, int N);
+// frame pipeline: the N - 2 views are synthesised inside the interlacer, sample by sample (no view buffers)
+void launch_synth_mux(const u8 *img_l, const u8 *img_r, const float *disp_l, const float *disp_r, const float *mask_l, const float *mask_r,
+                      const float *blend, u8 *out, int N, float y_interval, float inv_y_interval, int ymod, int Hin, int Win, int Hout,
+                      int Wout, int elem_sz, int variant);
 void launch_mux(const u8 *const *d_views, u8 *out, int N, float y_interval, float inv_y_interval, int ymod,
                 int Hin, int Win, int Hout, int Wout, int elem_sz, int variant);
 // aggregation on the matrix pipe (stm_kernels_aggm.hip): the frame pipeline's cost -> H -> V, V -> H + WTA

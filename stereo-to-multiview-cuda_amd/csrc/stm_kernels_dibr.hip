@@ -470,6 +470,97 @@ __global__ __launch_bounds__(256) void stm_k_mux(const u8 *const *__restrict__ v
     out[o + 1] = bilinear_u8(views[g_view], elem_sz, 1, xs, ys, Win, Hin);
     out[o + 2] = bilinear_u8(views[r_view], elem_sz, 2, xs, ys, Win, Hin);
 }
+// ------------------------------------------------------------------ view synthesis + interlacing in one pass (frame pipeline)
+// The frame pipeline used to write the N - 2 synthesised views (stm_k_view_synth_all: 37 MB at 1080p, 8 views) only for the
+// interlacer to pick ONE channel of THREE views per output pixel out of them (stm_k_mux).  Here an output pixel synthesises
+// exactly the samples it interlaces: per channel the view v = r, r + 1, r + 2 (mod N) of mux_multiview_kernel_2
+// (d_mux_multiview.cu:60-73) at the up to four neighbours of fast_bilinear_interp (:10-36) -- a neighbour whose weight is
+// exactly 0 is not evaluated (v * 0 = +0 and a + 0 = a for the finite, non-negative values involved: same result) -- each one
+// computed as d_dibr_dbm does (backward warp of both images, masks, blend: d_dibr_bwarp.cu:5-70, d_mux_common.cu:23-46), with
+// view 0 = the right image and view N - 1 = the left image (d_io.cu:182-183).  Same arithmetic, no view buffers.
+struct SynthArgs {
+    const u8 *img_l, *img_r;
+    const float *disp_l, *disp_r, *mask_l, *mask_r, *blend;
+};
+__device__ __forceinline__ u8 synth_sample(const SynthArgs &a, int N, int v, int c, int x, int y, int W, int elem_sz)
+{
+    const size_t row = (size_t)y * W, p = row + x;
+    if (v == 0) return a.img_r[p * elem_sz + c];
+    if (v == N - 1) return a.img_l[p * elem_sz + c];
+    const float wmax = (float)(W - 1);
+    const float shift = (float)(1.0 - ((1.0 * (double)(float)v) / ((double)(float)N - 1.0))); // d_io.cu:189
+    const float shift_l = -shift;                       // d_dibr_bwarp.cu:56
+    const float shift_r = (float)(1.0 - (double)shift); // :57
+    float sd = a.disp_r[p] * shift_l;
+    float fx = (float)x + sd;
+    const int sxl = (int)fminf(fmaxf(fx, 0.0f), wmax);
+    sd = a.disp_l[p] * shift_r;
+    fx = (float)x + sd;
+    const int sxr = (int)fminf(fmaxf(fx, 0.0f), wmax);
+    const float m = a.blend[p], one_m = 1.0f - m;
+    const u8 pa = (u8)((float)a.img_l[(row + sxl) * elem_sz + c] * a.mask_r[p]); // left-sourced pixel
+    const u8 pb = (u8)((float)a.img_r[(row + sxr) * elem_sz + c] * a.mask_l[p]); // right-sourced pixel
+    const float cb = one_m * (float)pa;
+    const float ca = m * (float)pb;
+    return (u8)((u8)cb + (u8)ca);
+}
+__device__ __forceinline__ u8 synth_bilinear(const SynthArgs &a, int N, int v, int c, float cx, float cy, int W, int H, int elem_sz)
+{
+    const int x0 = (int)floorf(cx), y0 = (int)floorf(cy);
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    const float wx = cx - (float)x0, wy = cy - (float)y0;
+    const float v00 = (float)synth_sample(a, N, v, c, x0, y0, W, elem_sz);
+    const float v01 = wx != 0.0f ? (float)synth_sample(a, N, v, c, x1, y0, W, elem_sz) : 0.0f;
+    float ta = v00 * (1.0f - wx);
+    float tb = v01 * wx;
+    const float top = ta + tb;
+    float bot = 0.0f;
+    if (wy != 0.0f) {
+        const float v10 = (float)synth_sample(a, N, v, c, x0, y1, W, elem_sz);
+        const float v11 = wx != 0.0f ? (float)synth_sample(a, N, v, c, x1, y1, W, elem_sz) : 0.0f;
+        ta = v10 * (1.0f - wx);
+        tb = v11 * wx;
+        bot = ta + tb;
+    }
+    ta = top * (1.0f - wy);
+    tb = bot * wy;
+    return (u8)(ta + tb);
+}
+__global__ __launch_bounds__(256) void stm_k_synth_mux(SynthArgs a, u8 *__restrict__ out, int N, float y_interval, float inv_y, int ymod,
+                                                       int Hin, int Win, int Hout, int Wout, int elem_sz, int variant)
+{
+    const int tx = blockIdx.x * 256 + threadIdx.x, ty = blockIdx.y;
+    if (tx >= Wout) return;
+    float xs = ((float)tx / (float)Wout) * (float)Win;
+    xs = fminf(fmaxf(xs, 0.0f), (float)(Win - 1));
+    float ys = ((float)ty / (float)Hout) * (float)Hin;
+    ys = fminf(fmaxf(ys, 0.0f), (float)(Hin - 1));
+    const float x_interval = (float)N;
+    float y_view = (float)(ty % ymod) + 1.0f;
+    y_view = y_view * x_interval;
+    y_view = (variant == 2) ? y_view * inv_y : y_view / y_interval; // d_mux_multiview.cu:62-63 vs :105-106
+    const int x_view = (tx * 3 + (int)y_view) % N;
+    int r_view = x_view;
+    if (r_view < 0) r_view += N;
+    int g_view = r_view + 1, b_view = r_view + 2;
+    if (g_view >= N) g_view -= N;
+    if (b_view >= N) b_view -= N;
+    const size_t o = ((size_t)tx + (size_t)ty * Wout) * elem_sz;
+    out[o + 0] = synth_bilinear(a, N, b_view, 0, xs, ys, Win, Hin, elem_sz);
+    out[o + 1] = synth_bilinear(a, N, g_view, 1, xs, ys, Win, Hin, elem_sz);
+    out[o + 2] = synth_bilinear(a, N, r_view, 2, xs, ys, Win, Hin, elem_sz);
+}
+void launch_synth_mux(const u8 *img_l, const u8 *img_r, const float *disp_l, const float *disp_r, const float *mask_l, const float *mask_r,
+                      const float *blend, u8 *out, int N, float y_interval, float inv_y_interval, int ymod, int Hin, int Win, int Hout,
+                      int Wout, int elem_sz, int variant)
+{
+    SynthArgs a{img_l, img_r, disp_l, disp_r, mask_l, mask_r, blend};
+    ProfScope p("synth_mux");
+    STM_LAUNCH(stm_k_synth_mux, dim3(cdiv(Wout, 256), Hout), dim3(256), 0, stream(), a, out, N, y_interval, inv_y_interval, ymod, Hin,
+               Win, Hout, Wout, elem_sz, variant);
+    STM_CHECK_LAUNCH();
+}
+
 void launch_mux(const u8 *const *d_views, u8 *out, int N, float y_interval, float inv_y_interval, int ymod, int Hin,
                 int Win, int Hout, int Wout, int elem_sz, int variant)
 {
