@@ -48,31 +48,49 @@ __global__ __launch_bounds__(256) void stm_k_widen_px(const uint32_t *__restrict
 // lcd, far tier when anchor-vs-current exceeds ucd.  `(float)int > float` is evaluated as int > floor(float),
 // which is the same predicate for every integer left-hand side.
 //   tg_near / tg_far = (512 + threshold) in every field, anchor = the wide anchor pixel.
-__device__ __forceinline__ int one_arm(const uint32_t *__restrict__ p, int stride, int kmax, int lsd, uint32_t tg_far,
-                                       uint32_t tg_near, uint32_t anchor)
+// Round 3: no per-lane early exit.  The round-2 loop left each lane at its first failing pixel, and the exec-mask
+// bookkeeping of that divergent exit cost 16 scalar instructions per step -- the kernel ran at 0.72 scalar instructions
+// per clock and CU, the scalar unit's limit (profiles/r03_pmc_sq_aggm.txt).  Here arm = min(kmax, first failing k) is
+// tracked with vector min / select only: k is wave-uniform, a lane that has failed (or left the image: its reads are
+// clamped to its last pixel) keeps computing tests whose outcome cannot lower its arm any more, and the whole wave leaves
+// once every lane is done (one ballot per four steps).
+//   pix4 = byte offset of the anchor in the plane, stride4 = byte distance of one step.
+__device__ __forceinline__ int one_arm(const uint32_t *__restrict__ plane, int pix4, int stride4, int kmax, int usd, int lsd,
+                                       uint32_t tg_far, uint32_t tg_near, uint32_t anchor)
 {
-    int arm = 0;
-    const int knear = min(kmax, lsd);
+    int arm = kmax; // no failure inside the image: the arm ends at usd or at the border
     const uint32_t anchor_n = anchor + tg_near;
     uint32_t prev = anchor, prev_t = anchor_n; // previous pixel and previous pixel + TG
+    const char *base = (const char *)plane;
     int k = 1;
-    for (; k <= knear; ++k) {
-        p += stride;
-        const uint32_t c = *p;
-        arm = k;
-        const uint32_t c_t = c + tg_near;
-        const uint32_t ok = (c_t - anchor) & (anchor_n - c) & (c_t - prev) & (prev_t - c) & W10_GUARD;
-        if (ok != W10_GUARD) return arm;
-        prev = c;
-        prev_t = c_t;
+    const int knear = min(usd, lsd);
+    while (k <= knear) {
+        if (__ballot(k <= arm) == 0) return arm; // every lane has failed or run out of image
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (k <= knear) { // uniform
+                const uint32_t c = *(const uint32_t *)(base + (pix4 + __mul24(min(k, kmax), stride4)));
+                const uint32_t c_t = c + tg_near;
+                const uint32_t ok = (c_t - anchor) & (anchor_n - c) & (c_t - prev) & (prev_t - c) & W10_GUARD;
+                arm = min(arm, ok != W10_GUARD ? k : 0x7fffffff);
+                prev = c;
+                prev_t = c_t;
+                ++k;
+            }
+        }
     }
     const uint32_t far_lo = tg_far - anchor, far_hi = anchor + tg_far;
-    for (; k <= kmax; ++k) {
-        p += stride;
-        const uint32_t c = *p;
-        arm = k;
-        const uint32_t ok = (c + far_lo) & (far_hi - c) & W10_GUARD;
-        if (ok != W10_GUARD) return arm;
+    while (k <= usd) {
+        if (__ballot(k <= arm) == 0) return arm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (k <= usd) {
+                const uint32_t c = *(const uint32_t *)(base + (pix4 + __mul24(min(k, kmax), stride4)));
+                const uint32_t ok = (c + far_lo) & (far_hi - c) & W10_GUARD;
+                arm = min(arm, ok != W10_GUARD ? k : 0x7fffffff);
+                ++k;
+            }
+        }
     }
     return arm;
 }
@@ -88,12 +106,12 @@ __global__ __launch_bounds__(256) void stm_k_cross_arms(ArmsArgs a, uint32_t tg_
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
     const int p = y * W + x;
-    const uint32_t *__restrict__ img = a.img[v] + p;
-    const uint32_t anchor = *img;
-    a.up[v][p] = (u8)one_arm(img, -W, min(usd, y), lsd, tg_far, tg_near, anchor);
-    a.down[v][p] = (u8)one_arm(img, W, min(usd, H - 1 - y), lsd, tg_far, tg_near, anchor);
-    a.left[v][p] = (u8)one_arm(img, -1, min(usd, x), lsd, tg_far, tg_near, anchor);
-    a.right[v][p] = (u8)one_arm(img, 1, min(usd, W - 1 - x), lsd, tg_far, tg_near, anchor);
+    const uint32_t *__restrict__ img = a.img[v];
+    const uint32_t anchor = img[p];
+    a.up[v][p] = (u8)one_arm(img, 4 * p, -4 * W, min(usd, y), usd, lsd, tg_far, tg_near, anchor);
+    a.down[v][p] = (u8)one_arm(img, 4 * p, 4 * W, min(usd, H - 1 - y), usd, lsd, tg_far, tg_near, anchor);
+    a.left[v][p] = (u8)one_arm(img, 4 * p, -4, min(usd, x), usd, lsd, tg_far, tg_near, anchor);
+    a.right[v][p] = (u8)one_arm(img, 4 * p, 4, min(usd, W - 1 - x), usd, lsd, tg_far, tg_near, anchor);
 }
 
 // threshold as the integer t with (int diff > threshold) <=> (diff > t), clamped to [-1, 255], times the field pattern
