@@ -108,10 +108,59 @@ __global__ __launch_bounds__(256) void stm_k_cross_arms(ArmsArgs a, uint32_t tg_
     const int p = y * W + x;
     const uint32_t *__restrict__ img = a.img[v];
     const uint32_t anchor = img[p];
-    a.up[v][p] = (u8)one_arm(img, 4 * p, -4 * W, min(usd, y), usd, lsd, tg_far, tg_near, anchor);
-    a.down[v][p] = (u8)one_arm(img, 4 * p, 4 * W, min(usd, H - 1 - y), usd, lsd, tg_far, tg_near, anchor);
-    a.left[v][p] = (u8)one_arm(img, 4 * p, -4, min(usd, x), usd, lsd, tg_far, tg_near, anchor);
-    a.right[v][p] = (u8)one_arm(img, 4 * p, 4, min(usd, W - 1 - x), usd, lsd, tg_far, tg_near, anchor);
+    // the four arms of a pixel walk together: four independent loads per step, one exit test for all of them
+    const char *base = (const char *)img;
+    const int pix4 = 4 * p;
+    const int st4[4] = {-4 * W, 4 * W, -4, 4};
+    const int kmax[4] = {min(usd, y), min(usd, H - 1 - y), min(usd, x), min(usd, W - 1 - x)};
+    int arm[4] = {kmax[0], kmax[1], kmax[2], kmax[3]};
+    const uint32_t anchor_n = anchor + tg_near;
+    uint32_t prev[4] = {anchor, anchor, anchor, anchor}, prev_t[4] = {anchor_n, anchor_n, anchor_n, anchor_n};
+    int k = 1;
+    const int knear = min(usd, lsd);
+    while (k <= knear) {
+        if (__ballot(k <= max(max(arm[0], arm[1]), max(arm[2], arm[3]))) == 0) break;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (k <= knear) { // uniform
+                uint32_t c[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) c[d] = *(const uint32_t *)(base + (pix4 + __mul24(min(k, kmax[d]), st4[d])));
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t c_t = c[d] + tg_near;
+                    const uint32_t ok = (c_t - anchor) & (anchor_n - c[d]) & (c_t - prev[d]) & (prev_t[d] - c[d]) & W10_GUARD;
+                    arm[d] = min(arm[d], ok != W10_GUARD ? k : 0x7fffffff);
+                    prev[d] = c[d];
+                    prev_t[d] = c_t;
+                }
+                ++k;
+            }
+        }
+    }
+    const uint32_t far_lo = tg_far - anchor, far_hi = anchor + tg_far;
+    k = max(k, knear + 1); // an early exit of the near tier means every arm is final: the far loop leaves at once
+    while (k <= usd) {
+        if (__ballot(k <= max(max(arm[0], arm[1]), max(arm[2], arm[3]))) == 0) break;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (k <= usd) {
+                uint32_t c[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) c[d] = *(const uint32_t *)(base + (pix4 + __mul24(min(k, kmax[d]), st4[d])));
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t ok = (c[d] + far_lo) & (far_hi - c[d]) & W10_GUARD;
+                    arm[d] = min(arm[d], ok != W10_GUARD ? k : 0x7fffffff);
+                }
+                ++k;
+            }
+        }
+    }
+    a.up[v][p] = (u8)arm[0];
+    a.down[v][p] = (u8)arm[1];
+    a.left[v][p] = (u8)arm[2];
+    a.right[v][p] = (u8)arm[3];
 }
 
 // threshold as the integer t with (int diff > threshold) <=> (diff > t), clamped to [-1, 255], times the field pattern
