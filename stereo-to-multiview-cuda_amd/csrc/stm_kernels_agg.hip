@@ -42,58 +42,19 @@ __global__ __launch_bounds__(256) void stm_k_widen_px(const uint32_t *__restrict
     wide[i] = (p & 0xffu) | ((p & 0xff00u) << 2) | ((p & 0xff0000u) << 4);
 }
 
-// One arm: walk k = 1..kmax pixels from the anchor (kmax = min(usd, distance to the border): the reference's
-// border test, d_ca_cross.cu:44-45, hoisted out of the loop).  The arm value is recorded BEFORE the colour
+// The arms of a pixel: walk k = 1..kmax pixels from the anchor in each direction (kmax = min(usd, distance to the border): the
+// reference's border test, d_ca_cross.cu:44-45, hoisted out of the loop).  The arm value is recorded BEFORE the colour
 // test (SURVEY A-Q9, :47-64): near tier (k <= lsd) stops when anchor-vs-current or previous-vs-current exceeds
 // lcd, far tier when anchor-vs-current exceeds ucd.  `(float)int > float` is evaluated as int > floor(float),
 // which is the same predicate for every integer left-hand side.
 //   tg_near / tg_far = (512 + threshold) in every field, anchor = the wide anchor pixel.
-// Round 3: no per-lane early exit.  The round-2 loop left each lane at its first failing pixel, and the exec-mask
-// bookkeeping of that divergent exit cost 16 scalar instructions per step -- the kernel ran at 0.72 scalar instructions
-// per clock and CU, the scalar unit's limit (profiles/r03_pmc_sq_aggm.txt).  Here arm = min(kmax, first failing k) is
-// tracked with vector min / select only: k is wave-uniform, a lane that has failed (or left the image: its reads are
-// clamped to its last pixel) keeps computing tests whose outcome cannot lower its arm any more, and the whole wave leaves
-// once every lane is done (one ballot per four steps).
-//   pix4 = byte offset of the anchor in the plane, stride4 = byte distance of one step.
-__device__ __forceinline__ int one_arm(const uint32_t *__restrict__ plane, int pix4, int stride4, int kmax, int usd, int lsd,
-                                       uint32_t tg_far, uint32_t tg_near, uint32_t anchor)
-{
-    int arm = kmax; // no failure inside the image: the arm ends at usd or at the border
-    const uint32_t anchor_n = anchor + tg_near;
-    uint32_t prev = anchor, prev_t = anchor_n; // previous pixel and previous pixel + TG
-    const char *base = (const char *)plane;
-    int k = 1;
-    const int knear = min(usd, lsd);
-    while (k <= knear) {
-        if (__ballot(k <= arm) == 0) return arm; // every lane has failed or run out of image
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (k <= knear) { // uniform
-                const uint32_t c = *(const uint32_t *)(base + (pix4 + __mul24(min(k, kmax), stride4)));
-                const uint32_t c_t = c + tg_near;
-                const uint32_t ok = (c_t - anchor) & (anchor_n - c) & (c_t - prev) & (prev_t - c) & W10_GUARD;
-                arm = min(arm, ok != W10_GUARD ? k : 0x7fffffff);
-                prev = c;
-                prev_t = c_t;
-                ++k;
-            }
-        }
-    }
-    const uint32_t far_lo = tg_far - anchor, far_hi = anchor + tg_far;
-    while (k <= usd) {
-        if (__ballot(k <= arm) == 0) return arm;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (k <= usd) {
-                const uint32_t c = *(const uint32_t *)(base + (pix4 + __mul24(min(k, kmax), stride4)));
-                const uint32_t ok = (c + far_lo) & (far_hi - c) & W10_GUARD;
-                arm = min(arm, ok != W10_GUARD ? k : 0x7fffffff);
-                ++k;
-            }
-        }
-    }
-    return arm;
-}
+// Round 3: no per-lane early exit, four arms at once.  The round-2 loop left each lane at its first failing pixel, one arm
+// after the other, and the exec-mask bookkeeping of that divergent exit cost 16 scalar instructions per step -- the kernel ran
+// at 0.72 scalar instructions per clock and CU, the scalar unit's limit (profiles/r03_pmc_sq_aggm.txt).  Here
+// arm = min(kmax, first failing k) is tracked with vector min / select only: k is wave-uniform, a lane that has failed (or left
+// the image: its reads are clamped to its last pixel) keeps computing tests whose outcome cannot lower its arm any more, the
+// four directions issue their loads together, and the whole wave leaves once every arm of every lane is final (one ballot
+// per two steps).  0.184 -> 0.137 ms per frame.
 
 struct ArmsArgs {
     const uint32_t *img[2]; // wide pixels
