@@ -737,7 +737,8 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
         const u8 *u[2] = {al.up, ar.up}, *d[2] = {al.down, ar.down}, *l[2] = {al.left, ar.left}, *r[2] = {al.right, ar.right};
         launch_irv(2, dv, ov, u, d, l, r, thresh_s, thresh_h, H, W, D, zero_disp, usd, 5, true);
     }
-    launch_bilateral2(wl, d_disp_l, wr, d_disp_r, gauss2d_table(7, 10.0f), gauss1d_table(D, 5.0f), 7, H, W, D); // :150-151  (7, 5, 10)
+    // the maps are this pipeline's own WTA / region-voting output: integer-valued, any two of them differ by at most D - 1
+    launch_bilateral2(wl, d_disp_l, wr, d_disp_r, gauss2d_table(7, 10.0f), gauss1d_table(D, 5.0f), 7, H, W, D, true); // :150-151  (7, 5, 10)
 }
 
 // hit maps -> bleed -> masks -> N-2 views -> interlace (d_io.cu:160-205)

@@ -160,8 +160,10 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
                 int H, int W, int D, int zd, int usd, int iterations, bool device_flavour);
 void launch_bilateral(const float *in, float *out, const float *spatial, const float *color,
                       int radius, int H, int W, int D);
+// integer_maps: both maps hold integer-valued disparities any two of which differ by less than D (the frame pipeline's own
+// WTA / region-voting output)
 void launch_bilateral2(const float *in_a, float *out_a, const float *in_b, float *out_b, const float *spatial, const float *color,
-                       int radius, int H, int W, int D);
+                       int radius, int H, int W, int D, bool integer_maps = false);
 void launch_gaussian_max(const float *in, float *out, const float *spatial, int radius, float sigma, int H, int W,
                          bool invert_input);
 // DIBR + mux (stm_kernels_dibr.hip)

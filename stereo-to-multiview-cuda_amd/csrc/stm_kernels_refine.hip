@@ -634,7 +634,14 @@ __global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_gaussian_max_r(const float
     }
 }
 
-template <int R>
+// INTMAP (the frame pipeline's call): the maps hold integer-valued disparities whose differences stay inside the colour LUT --
+// WTA writes d - zd, region voting bin - zd, so any two values differ by at most D - 1 = ncolor - 1.  The kernel is bound by
+// vector-instruction issue (95 M wave instructions, every one 4 cycles: profiles/r03_pmc_sq_aggm.txt), 13 per pixel pair and tap,
+// of which 8 only produce the LUT address (subtract, |.| -> int, clamp, shift, twice).  With a second tile holding 4 x (value +
+// bias) as integers the LUT's BYTE OFFSET is one v_sad_u32 per pixel (|4a - 4b| = 4 |a - b|, exact), no clamp needed; weights
+// and both running sums are computed exactly as before from the float tile.  The per-stage filter_bilateral_1 (arbitrary
+// floats) keeps the general form.
+template <int R, bool INTMAP>
 __global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_bilateral_r(const float *__restrict__ in0, float *__restrict__ out0,
                                                                  const float *__restrict__ in1, float *__restrict__ out1,
                                                                  const float *__restrict__ spatial,
@@ -645,14 +652,18 @@ __global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_bilateral_r(const float *_
     constexpr int KW = 2 * R + 1, NF = (KW + 3 + 3) / 4 * 4;
     constexpr int TW = (SF_TX * 4 + 2 * R + 3) / 4 * 4 + 4, TH = SF_TY + 2 * R;
     __shared__ float4 tile4[TH * TW / 4];
+    __shared__ uint4 itile4[INTMAP ? TH * TW / 4 : 1];
     extern __shared__ float ck[]; // colour LUT, ncolor entries
     float *tile = (float *)tile4;
+    uint32_t *itile = (uint32_t *)itile4;
     const int tid = threadIdx.y * SF_TX + threadIdx.x;
     const int x0 = blockIdx.x * SF_TX * 4, y0 = blockIdx.y * SF_TY;
     for (int i = tid; i < TH * TW; i += SF_TX * SF_TY) {
         const int ty = i / TW, tx = i - ty * TW;
         const int gx = min(max(x0 + tx - R, 0), W - 1), gy = min(max(y0 + ty - R, 0), H - 1);
-        tile[i] = in[(size_t)gy * W + gx];
+        const float t = in[(size_t)gy * W + gx];
+        tile[i] = t;
+        if (INTMAP) itile[i] = (uint32_t)(((int)t + (1 << 20)) * 4);
     }
     for (int i = tid; i < ncolor; i += SF_TX * SF_TY) ck[i] = color[i];
     __syncthreads();
@@ -662,16 +673,26 @@ __global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_bilateral_r(const float *_
     // (two pixels per instruction, each component rounded exactly like the scalar operation it replaces).
     typedef float f2 __attribute__((ext_vector_type(2)));
     float va[4];
+    uint32_t ia[4];
     f2 res[2] = {{0.f, 0.f}, {0.f, 0.f}}, norm[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) va[i] = tile[(threadIdx.y + R) * TW + threadIdx.x * 4 + i + R];
+    for (int i = 0; i < 4; ++i) {
+        va[i] = tile[(threadIdx.y + R) * TW + threadIdx.x * 4 + i + R];
+        ia[i] = INTMAP ? itile[(threadIdx.y + R) * TW + threadIdx.x * 4 + i + R] : 0u;
+    }
     for (int y = 0; y < KW; ++y) {
         float row[NF];
+        uint32_t irow[NF];
         const float4 *src = (const float4 *)(tile + (threadIdx.y + y) * TW + threadIdx.x * 4);
+        const uint4 *isrc = (const uint4 *)(itile + (threadIdx.y + y) * TW + threadIdx.x * 4);
 #pragma unroll
         for (int j = 0; j < NF / 4; ++j) {
             const float4 t = src[j];
             row[4 * j] = t.x; row[4 * j + 1] = t.y; row[4 * j + 2] = t.z; row[4 * j + 3] = t.w;
+            if (INTMAP) {
+                const uint4 u = isrc[j];
+                irow[4 * j] = u.x; irow[4 * j + 1] = u.y; irow[4 * j + 2] = u.z; irow[4 * j + 3] = u.w;
+            }
         }
         const float *krow = spatial + y * KW;
 #pragma unroll
@@ -681,10 +702,18 @@ __global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_bilateral_r(const float *_
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f2 vs = {row[x + 2 * h], row[x + 2 * h + 1]};
-                int c0 = (int)fabsf(va[2 * h] - vs.x), c1 = (int)fabsf(va[2 * h + 1] - vs.y); // d_filter_bilateral.cu:295
-                c0 = min(c0, ncolor - 1);
-                c1 = min(c1, ncolor - 1);
-                const f2 gc = {ck[c0], ck[c1]};
+                f2 gc;
+                if (INTMAP) {
+                    uint32_t b0, b1; // byte offsets into the LUT: 4 |a - b|
+                    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(b0) : "v"(ia[2 * h]), "v"(irow[x + 2 * h]));
+                    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(b1) : "v"(ia[2 * h + 1]), "v"(irow[x + 2 * h + 1]));
+                    gc = f2{*(const float *)((const char *)ck + b0), *(const float *)((const char *)ck + b1)};
+                } else {
+                    int c0 = (int)fabsf(va[2 * h] - vs.x), c1 = (int)fabsf(va[2 * h + 1] - vs.y); // d_filter_bilateral.cu:295
+                    c0 = min(c0, ncolor - 1);
+                    c1 = min(c1, ncolor - 1);
+                    gc = f2{ck[c0], ck[c1]};
+                }
                 const f2 w = gs2 * gc;
                 norm[h] = norm[h] + w;
                 const f2 t = vs * w;
@@ -753,7 +782,7 @@ __global__ __launch_bounds__(ST_TX *ST_TY) void stm_k_bilateral(const float *__r
 
 // the frame pipeline's two maps (left, right) in one launch of the radius-7 kernel
 void launch_bilateral2(const float *in_a, float *out_a, const float *in_b, float *out_b, const float *spatial, const float *color,
-                       int radius, int H, int W, int D)
+                       int radius, int H, int W, int D, bool integer_maps)
 {
     if (radius != 7) {
         launch_bilateral(in_a, out_a, spatial, color, radius, H, W, D);
@@ -761,8 +790,12 @@ void launch_bilateral2(const float *in_a, float *out_a, const float *in_b, float
         return;
     }
     ProfScope p("bilateral");
-    STM_LAUNCH(stm_k_bilateral_r<7>, dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY), 2), dim3(SF_TX, SF_TY), (size_t)D * 4, stream(), in_a, out_a,
-               in_b, out_b, spatial, color, H, W, D);
+    if (integer_maps)
+        STM_LAUNCH((stm_k_bilateral_r<7, true>), dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY), 2), dim3(SF_TX, SF_TY), (size_t)D * 4, stream(), in_a, out_a,
+                   in_b, out_b, spatial, color, H, W, D);
+    else
+        STM_LAUNCH((stm_k_bilateral_r<7, false>), dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY), 2), dim3(SF_TX, SF_TY), (size_t)D * 4, stream(), in_a, out_a,
+                   in_b, out_b, spatial, color, H, W, D);
     STM_CHECK_LAUNCH();
 }
 
@@ -771,7 +804,7 @@ void launch_bilateral(const float *in, float *out, const float *spatial, const f
 {
     if (radius == 7) {
         ProfScope p("bilateral");
-        STM_LAUNCH(stm_k_bilateral_r<7>, dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY)), dim3(SF_TX, SF_TY), (size_t)D * 4, stream(),
+        STM_LAUNCH((stm_k_bilateral_r<7, false>), dim3(cdiv(W, SF_TX * 4), cdiv(H, SF_TY)), dim3(SF_TX, SF_TY), (size_t)D * 4, stream(),
                            in, out, in, out, spatial, color, H, W, D);
         STM_CHECK_LAUNCH();
         return;
