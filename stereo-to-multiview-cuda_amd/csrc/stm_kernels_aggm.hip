@@ -859,14 +859,14 @@ __global__ __launch_bounds__(128 * NTP) void stm_k_pq_v12t(PQViews v, const uint
     const size_t strip = ((size_t)c * H * G + g) * 16; // float4 index of (chunk c, row 0, group g, hypothesis 0)
     const uint32_t range = (uint32_t)(H - 1) * (uint32_t)rsb + 256u;
     for (int i = tid; i < (RQ1 + RQ2) * 64; i += NTH) lds4[i] = f4{0.f, 0.f, 0.f, 0.f}; // masked steps multiply ring contents by 0
-    ctab32 *trow = (ctab32 *)(uintptr_t)(wtab + ((size_t)view * nT * G + g) * rec); // + u * G * rec: record of tile u
-    const size_t tstep = (size_t)G * rec;
+    ctab32 *trow = (ctab32 *)(uintptr_t)(wtab + (STM_DBG(dbg, 8) ? (size_t)0 : ((size_t)view * nT * G + g) * rec)); // + u * G * rec: record of tile u
+    const size_t tstep = STM_DBG(dbg, 8) ? (size_t)0 : (size_t)G * rec; // timing knob 8: every tile reads one record (scalar-cache hits only)
     // records of the tiles this wave sweeps: headers are fetched one step ahead (tiles past the image: the last tile's record, unused)
 #define STM_V12_HDR(U, K0_, NIT_)                                                \
     {                                                                            \
         ctab32 *r_ = trow + (size_t)min(max(U, 0), nT - 1) * tstep;                       \
         K0_ = (int)r_[0];                                                        \
-        NIT_ = STM_DBG(dbg, 1) ? 0 : STM_DBG(dbg, 2) ? 12 : (int)r_[1];          \
+        NIT_ = STM_DBG(dbg, 1) ? 0 : STM_DBG(dbg, 2) ? 12 : STM_DBG(dbg, 8) ? 12 : (int)r_[1];          \
     }
     __syncthreads();
     if (!second) {
@@ -1076,7 +1076,7 @@ static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const 
     }
     {
         // fused vertical kernel; the window table is built once per call for all views
-        constexpr int NTP = 3, TS = 16 * NTP;
+        constexpr int NTP = 3, TS = 16 * NTP; // 2 and 4 tiles per pass and step: 0.729 ms each against 0.679
         const int UQ = (usd + 3) & ~3, nT = (H + 15) / 16;
         const int rec = 8 + 8 * ((2 * usd + 21) / 4 + 2); // header + the longest sweep + one quad of read-ahead
         const int LAG = (UQ + TS - 1) / TS + 1;
