@@ -320,7 +320,7 @@ __global__ __launch_bounds__(IC_T) void stm_k_irv_compact(IrvArgs a, uint32_t HW
 
 constexpr int IV_WAVES = 2;     // waves per block
 constexpr int IV_PX_PER_BLOCK = 256; // grid per view = pixels / this (see launch_irv)
-constexpr int IV_U = 4;         // row pairs whose loads are in flight together
+constexpr int IV_U = 8;         // region rows whose loads are in flight together
 
 // max / sum over the 64 lanes as a scalar, on the DPP path (six ALU ops with a DPP operand; lanes without a source keep
 // their value / add 0): the LDS round trips of a shuffle reduction are what this kernel cannot afford
@@ -369,12 +369,11 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 // outliers whose cross regions overlap in cache (re-listing through atomics scrambled that and cost 40 %).
 // Pruning: an outlier whose cross region saw no accepted pixel in the previous iteration would repeat its
 // previous vote exactly (the vote is a pure function of the region) and be rejected again, so it is skipped;
-// `dirty` holds one byte per 64x64 tile and iteration.
+// `dirty` holds one byte per tile (16x16 for usd <= 48) and iteration.
 // paper_ratio: accept on (winning COUNT) / S > thresh_h (Mei et al.) instead of the reference's (winning BIN INDEX) / S
 // (d_dr_irv.cu:36, SURVEY A-Q17 iv); off by default.
-constexpr int IV_TILE = 64;
 __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int it, int thresh_s, float thresh_h, int H, int W,
-                                                                int nb, int zd, int usd, int tiles_x, int tiles_y, int paper_ratio)
+                                                                int nb, int zd, int usd, int tiles_x, int tiles_y, int tile_sh, int paper_ratio)
 {
     extern __shared__ uint32_t irv_lds[]; // per wave: uint4 slots[nb + 1 + 64]: slot 0 = "other", 1 + b = bin b, then one per lane
     const int v = blockIdx.y;
@@ -416,11 +415,11 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
         cd = min(cd, H - 1 - gy); // caller who passes inconsistent arms from reading outside the planes
         cu = __builtin_amdgcn_readfirstlane(cu);
         cd = __builtin_amdgcn_readfirstlane(cd);
-        if (dirty) { // bounding box of the region = [gx-usd, gx+usd] x [gy-cu, gy+cd]: at most 3x3 tiles of 64
-            const int tx0 = max(gx - usd, 0) / IV_TILE, tx1 = min(gx + usd, W - 1) / IV_TILE;
-            const int ty0 = (gy - cu) / IV_TILE, ty1 = (gy + cd) / IV_TILE;
+        if (dirty) { // bounding box of the region = [gx-usd, gx+usd] x [gy-cu, gy+cd]: at most 8x8 tiles (launch_irv picks the tile size)
+            const int tx0 = max(gx - usd, 0) >> tile_sh, tx1 = min(gx + usd, W - 1) >> tile_sh;
+            const int ty0 = (gy - cu) >> tile_sh, ty1 = (gy + cd) >> tile_sh;
             const int nx = tx1 - tx0 + 1, nt = nx * (ty1 - ty0 + 1);
-            int d = nt > 64; // more tiles than lanes (usd > 95): do not prune
+            int d = nt > 64; // more tiles than lanes (cannot happen with launch_irv's tile size): do not prune
             if (lane < nt) d = dirty[(ty0 + lane / nx) * tiles_x + tx0 + lane % nx];
             if (__ballot(d != 0) == 0) continue; // same region contents as last time -> same vote -> rejected again
         }
@@ -494,9 +493,12 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
                 a.outl[v][p] = 0;
                 disp[p] = (float)max_d;
                 code_nx[p] = nc;
-                dirty_out[(gy / IV_TILE) * tiles_x + gx / IV_TILE] = 1; // same value from every writer
+                dirty_out[(gy >> tile_sh) * tiles_x + (gx >> tile_sh)] = 1; // same value from every writer
                 list[i] = (uint32_t)p | IV_ACCEPTED;
             }
+        } else if (!paper_ratio && total > 0 && !((float)max(nb - 1, (int)own + zd) / (float)total > thresh_h)) {
+            // S only grows and the numerator never exceeds this bound (see stm_k_irv_rowcount): rejected now = rejected for good
+            if (lane == 0) list[i] = IV_DEAD;
         }
     }
 }
@@ -514,7 +516,10 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
     // host flavour (d_dr_irv.cu:344-353): one vote, then `iterations` applies of which only the first can change anything
     const int rounds = device_flavour ? iterations : (iterations > 0 ? 1 : 0);
     IrvArgs a;
-    const int tiles_x = cdiv(W, IV_TILE), tiles_y = cdiv(H, IV_TILE);
+    // dirty tiles: the smallest power of two >= 16 for which a region's bounding box (2 usd + 1 wide) spans at most 8 x 8 tiles
+    int tile_sh = 4;
+    while ((2 * std::min(usd, 255)) / (1 << tile_sh) + 2 > 8) ++tile_sh;
+    const int tiles_x = cdiv(W, 1 << tile_sh), tiles_y = cdiv(H, 1 << tile_sh);
     const size_t dirty_sz = (size_t)(rounds + 1) * tiles_x * tiles_y;
     const size_t ncount = 4; // per view: list length
     const size_t nwords = ncount + (2 * dirty_sz + 3) / 4;
@@ -569,7 +574,7 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
     const int iv_blocks = (int)std::min<size_t>(std::max<size_t>((HW + IV_PX_PER_BLOCK - 1) / IV_PX_PER_BLOCK, 256), 32768);
     for (int it = 0; it < rounds; ++it) {
         STM_LAUNCH(stm_k_irv_vote, dim3(iv_blocks, nviews), dim3(64 * IV_WAVES), smem, stream(), a, it, thresh_s, thresh_h, H,
-                           W, nb, zd, usd, tiles_x, tiles_y, irv_paper_ratio());
+                           W, nb, zd, usd, tiles_x, tiles_y, tile_sh, irv_paper_ratio());
         STM_CHECK_LAUNCH();
     }
 }

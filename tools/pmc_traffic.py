@@ -39,9 +39,11 @@ def short(name):
         if len(args) >= 5 and args[4] == "true":
             return "agg_h_cost"                   # <..., COST = true>: costs computed on the fly, no volume read
         return "agg_h"
-    for k in ("agg_v", "cost_init", "cross_arms", "irv_vote", "bilateral", "gaussian_max", "view_synth", "mux"):
+    for k in ("agg_v", "cost_init", "cross_arms", "irv_vote", "bilateral", "gaussian_max", "view_synth", "synth_mux", "demux"):
         if k in n:
             return k
+    if "mux" in n:
+        return "mux"
     return n
 
 
