@@ -235,13 +235,19 @@ __global__ __launch_bounds__(64 * NW) void stm_k_pq_h(PQViews v, int D, int zd, 
                 for (int cl = 0; cl < 4; ++cl) {
                     const int d = (c0 + cl) * 16 + dd;
                     f4 val = zero4;
-                    if (d < D) {
+                    if (c0 + cl < NC) { // uniform; d < 16 NC <= D + 15: inside the staged range (pad).  Branch-free per lane: the table
+                                        // reads of a chunk are issued together, pixels outside the row / hypotheses >= D are zeroed by selects
                         const uint2 *oth = s_oth + gi * 4 + sgn * (d - zd) + pad;
                         const uint2 q0 = oth[0], q1 = oth[1], q2 = oth[2], q3 = oth[3];
-                        if (in0) val.x = s_lut_ad[__builtin_amdgcn_sad_u8(o0.x, q0.x, 0u)] + s_lut_c[hamdist_q1(o0.y, q0.y)];
-                        if (in1) val.y = s_lut_ad[__builtin_amdgcn_sad_u8(o1.x, q1.x, 0u)] + s_lut_c[hamdist_q1(o1.y, q1.y)];
-                        if (in2) val.z = s_lut_ad[__builtin_amdgcn_sad_u8(o2.x, q2.x, 0u)] + s_lut_c[hamdist_q1(o2.y, q2.y)];
-                        if (in3) val.w = s_lut_ad[__builtin_amdgcn_sad_u8(o3.x, q3.x, 0u)] + s_lut_c[hamdist_q1(o3.y, q3.y)];
+                        const float a0 = s_lut_ad[__builtin_amdgcn_sad_u8(o0.x, q0.x, 0u)], e0 = s_lut_c[hamdist_q1(o0.y, q0.y)];
+                        const float a1 = s_lut_ad[__builtin_amdgcn_sad_u8(o1.x, q1.x, 0u)], e1 = s_lut_c[hamdist_q1(o1.y, q1.y)];
+                        const float a2 = s_lut_ad[__builtin_amdgcn_sad_u8(o2.x, q2.x, 0u)], e2 = s_lut_c[hamdist_q1(o2.y, q2.y)];
+                        const float a3 = s_lut_ad[__builtin_amdgcn_sad_u8(o3.x, q3.x, 0u)], e3 = s_lut_c[hamdist_q1(o3.y, q3.y)];
+                        const bool dok = d < D;
+                        val.x = (in0 && dok) ? a0 + e0 : 0.f;
+                        val.y = (in1 && dok) ? a1 + e1 : 0.f;
+                        val.z = (in2 && dok) ? a2 + e2 : 0.f;
+                        val.w = (in3 && dok) ? a3 + e3 : 0.f;
                     }
                     tile[cl * NG * 16 + rr] = val;
                 }
@@ -358,6 +364,7 @@ __global__ __launch_bounds__(64 * NW, (3 * NW) / 4) void stm_k_pq_hs(PQViews v, 
     const int NG = 4 * NW + 2 * HG, NJ = NG >> 2;
     f4 *tile = lds4; // [4 chunks][NJ slots][4 groups][16 hypotheses]
     uint32_t *sn = (uint32_t *)(tile + 4 * NG * 16);
+    int2 *sg = (int2 *)(sn + TX); // per wave tile: first group and length of its sweep
     const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lb = l >> 4, dd = l & 15;
     // block -> (view, row, part of the row)
@@ -391,7 +398,13 @@ __global__ __launch_bounds__(64 * NW, (3 * NW) / 4) void stm_k_pq_hs(PQViews v, 
     if (tid < TX) {                                                                                                        \
         const int x = (S) * TX + tid, org = (S) * TX - 4 * HG;                                                             \
         /* window [x - armL, x + armR) relative to the segment's first tile pixel (d_ca_cross_sum.cu:277-289); past the row: empty */ \
-        sn[tid] = x < W ? ((uint32_t)(x - aLn - org) | ((uint32_t)(aLn + aRn) << 16)) : (uint32_t)(x - org);              \
+        const int srel_ = x < W ? x - aLn - org : x - org, nn_ = x < W ? aLn + aRn : 0;                                    \
+        sn[tid] = (uint32_t)srel_ | ((uint32_t)nn_ << 16);                                                                 \
+        /* the sweep of the wave that owns these 16 pixels (a DPP row): first group, number of groups */                   \
+        int lo_ = nn_ ? (srel_ >> 2) : 0x7fffffff, hi_ = nn_ ? ((srel_ + nn_ + 3) >> 2) : -0x7fffffff;                     \
+        lo_ = min(lo_, row_ror_i<8>(lo_)); lo_ = min(lo_, row_ror_i<4>(lo_)); lo_ = min(lo_, row_ror_i<2>(lo_)); lo_ = min(lo_, row_ror_i<1>(lo_)); \
+        hi_ = max(hi_, row_ror_i<8>(hi_)); hi_ = max(hi_, row_ror_i<4>(hi_)); hi_ = max(hi_, row_ror_i<2>(hi_)); hi_ = max(hi_, row_ror_i<1>(hi_)); \
+        if ((tid & 15) == 0) sg[tid >> 4] = make_int2(lo_, hi_ - lo_);                                                     \
     }
     // first segment: the whole tile, pieces NW seg0 .. NW seg0 + NJ - 1 of every chunk, KP per wave and round
     {
@@ -426,12 +439,10 @@ __global__ __launch_bounds__(64 * NW, (3 * NW) / 4) void stm_k_pq_hs(PQViews v, 
         if (X0 < W) { // uniform per wave
             const uint32_t e = sn[16 * w + dd]; // mask lanes: pixel dd of the wave
             const int srel = (int)(e & 0xffffu), nn = (int)(e >> 16);
-            const int G0r = wave_min_i(nn ? (srel >> 2) : 0x7fffffff);
-            const int Gend = wave_max_i(nn ? ((srel + nn + 3) >> 2) : -0x7fffffff);
-            const int n_it = STM_DBG(dbg, 1) ? 0 : STM_DBG(dbg, 2) ? 11 : Gend - G0r; // <= 0 when every window of the wave is empty
+            const int2 sgw = sg[w]; // first group of the wave's sweep, its length in groups (STM_HS_SN)
+            const int G0r = __builtin_amdgcn_readfirstlane(sgw.x);
+            const int n_it = STM_DBG(dbg, 1) ? 0 : STM_DBG(dbg, 2) ? 11 : __builtin_amdgcn_readfirstlane(sgw.y); // <= 0 when every window of the wave is empty
             f16v acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             if (n_it > 0) {
                 int gs = 4 * slot0 + G0r; // ring position (in groups) of the first group of the sweep
                 if (gs >= NG) gs -= NG;
@@ -455,16 +466,29 @@ __global__ __launch_bounds__(64 * NW, (3 * NW) / 4) void stm_k_pq_hs(PQViews v, 
     }
                 f4 ca, cb;
                 STM_HS_NEXT(ca)
-                int it = 0;
-                for (; it + 2 <= n_it; it += 2) {
-                    STM_HS_NEXT(cb)
-                    STM_HS_MFMA(ca)
-                    STM_HS_NEXT(ca) // on the last trip one group past the sweep: any ring slot, unused
-                    STM_HS_MFMA(cb)
+                STM_HS_NEXT(cb) // a sweep of one group: one group past it (any ring slot, unused)
+                {   // the first MFMA takes the constant 0 as its accumulator input: no register is cleared
+                    const float m = ((unsigned)t < (unsigned)nn) ? 1.0f : 0.0f;
+                    t += 4;
+                    const f16v z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc = STM_MFMA16(m, ca.x, z, 0);
+                    acc = STM_MFMA16(m, ca.y, acc, 1);
+                    acc = STM_MFMA16(m, ca.z, acc, 2);
+                    acc = STM_MFMA16(m, ca.w, acc, 3);
                 }
-                if (it < n_it) STM_HS_MFMA(ca)
+                int it = 1;
+                for (; it + 2 <= n_it; it += 2) {
+                    STM_HS_NEXT(ca)
+                    STM_HS_MFMA(cb)
+                    STM_HS_NEXT(cb) // on the last trip one group past the sweep: any ring slot, unused
+                    STM_HS_MFMA(ca)
+                }
+                if (it < n_it) STM_HS_MFMA(cb)
 #undef STM_HS_NEXT
 #undef STM_HS_MFMA
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             }
             // registers 4b..4b+3 of lane 16q + n = out[pixels X0 + 4q .. +3][hypothesis 16 b + n]
             if (!WTA) {
@@ -492,12 +516,15 @@ __global__ __launch_bounds__(64 * NW, (3 * NW) / 4) void stm_k_pq_hs(PQViews v, 
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(disp + row), 0, (uint32_t)W * 4u, 0x00020000);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float m = bc[i];
-                    m = fminf(m, row_ror_f<8>(m));
-                    m = fminf(m, row_ror_f<4>(m));
-                    m = fminf(m, row_ror_f<2>(m));
-                    m = fminf(m, row_ror_f<1>(m));
-                    int cand = (bc[i] == m) ? bd[i] : 0x7fffffff;
+                    // aggregated costs are sums of non-negative terms (rho >= 0, masked steps add +0): never negative, never NaN,
+                    // so the order of the floats is the order of their bit patterns and the minimum is four v_min_i32 with a DPP operand
+                    const int bi = __builtin_bit_cast(int, bc[i]);
+                    int m = bi;
+                    m = min(m, row_ror_i<8>(m));
+                    m = min(m, row_ror_i<4>(m));
+                    m = min(m, row_ror_i<2>(m));
+                    m = min(m, row_ror_i<1>(m));
+                    int cand = (bi == m) ? bd[i] : 0x7fffffff;
                     cand = min(cand, row_ror_i<8>(cand));
                     cand = min(cand, row_ror_i<4>(cand));
                     cand = min(cand, row_ror_i<2>(cand));
@@ -544,8 +571,9 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void stm_k_pq_hc(PQViews v, 
     const int NG = 4 * NW + 2 * HG, NJ = NG >> 2;
     f4 *tile = lds4; // [4 chunks][NJ slots][4 groups][16 hypotheses]
     uint32_t *sn = (uint32_t *)(tile + 4 * NG * 16);
+    int2 *sg = (int2 *)(sn + TX); // per wave tile: first group and length of its sweep
     const int SO = NEWPX + 2 * pad; // other-image pixels staged per segment
-    uint2 *s_own = (uint2 *)(sn + TX), *s_oth = s_own + 2 * NEWPX; // two buffers each: [2][NEWPX], [2][SO]
+    uint2 *s_own = (uint2 *)(sg + NW), *s_oth = s_own + 2 * NEWPX; // two buffers each: [2][NEWPX], [2][SO]
     float *s_lut_ad = (float *)(s_oth + 2 * SO), *s_lut_c = s_lut_ad + 768;
     const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lb = l >> 4, dd = l & 15;
@@ -594,16 +622,23 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void stm_k_pq_hc(PQViews v, 
         const uint2 o0 = own[0], o1 = own[1], o2 = own[2], o3 = own[3];                                                   \
         const bool in0 = x0g >= 0 && x0g < W, in1 = x0g + 1 >= 0 && x0g + 1 < W, in2 = x0g + 2 >= 0 && x0g + 2 < W,       \
                    in3 = x0g + 3 >= 0 && x0g + 3 < W;                                                                     \
+        /* branch-free per lane: every staged pixel and table entry exists (the staging clamps to the row), so all table */ \
+        /* reads of a chunk are issued together and pixels outside the row / hypotheses >= D are zeroed by selects       */ \
         _Pragma("unroll") for (int cl = 0; cl < 4; ++cl) {                                                                \
-            const int d = cl * 16 + dd;                                                                                   \
             f4 val = {0.f, 0.f, 0.f, 0.f};                                                                                \
-            if (d < D) {                                                                                                  \
+            if (cl < NC) { /* uniform */                                                                                  \
+                const int d = cl * 16 + dd; /* < 16 NC <= D + 15: inside the staged range (pad) */                         \
                 const uint2 *oth = s_oth + (B) * SO + gi * 4 + sgn * (d - zd) + pad;                                      \
                 const uint2 q0 = oth[0], q1 = oth[1], q2 = oth[2], q3 = oth[3];                                           \
-                if (in0) val.x = s_lut_ad[__builtin_amdgcn_sad_u8(o0.x, q0.x, 0u)] + s_lut_c[hamdist_q1(o0.y, q0.y)];     \
-                if (in1) val.y = s_lut_ad[__builtin_amdgcn_sad_u8(o1.x, q1.x, 0u)] + s_lut_c[hamdist_q1(o1.y, q1.y)];     \
-                if (in2) val.z = s_lut_ad[__builtin_amdgcn_sad_u8(o2.x, q2.x, 0u)] + s_lut_c[hamdist_q1(o2.y, q2.y)];     \
-                if (in3) val.w = s_lut_ad[__builtin_amdgcn_sad_u8(o3.x, q3.x, 0u)] + s_lut_c[hamdist_q1(o3.y, q3.y)];     \
+                const float a0 = s_lut_ad[__builtin_amdgcn_sad_u8(o0.x, q0.x, 0u)], c0 = s_lut_c[hamdist_q1(o0.y, q0.y)]; \
+                const float a1 = s_lut_ad[__builtin_amdgcn_sad_u8(o1.x, q1.x, 0u)], c1 = s_lut_c[hamdist_q1(o1.y, q1.y)]; \
+                const float a2 = s_lut_ad[__builtin_amdgcn_sad_u8(o2.x, q2.x, 0u)], c2 = s_lut_c[hamdist_q1(o2.y, q2.y)]; \
+                const float a3 = s_lut_ad[__builtin_amdgcn_sad_u8(o3.x, q3.x, 0u)], c3 = s_lut_c[hamdist_q1(o3.y, q3.y)]; \
+                const bool dok = d < D;                                                                                   \
+                val.x = (in0 && dok) ? a0 + c0 : 0.f;                                                                     \
+                val.y = (in1 && dok) ? a1 + c1 : 0.f;                                                                     \
+                val.z = (in2 && dok) ? a2 + c2 : 0.f;                                                                     \
+                val.w = (in3 && dok) ? a3 + c3 : 0.f;                                                                     \
             }                                                                                                             \
             cst[cl] = val;                                                                                                \
         }                                                                                                                 \
@@ -617,7 +652,14 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void stm_k_pq_hc(PQViews v, 
 #define STM_HC_SN(S)                                                                                                       \
     if (tid < TX) {                                                                                                        \
         const int x = (S) * TX + tid, org = (S) * TX - 4 * HG;                                                             \
-        sn[tid] = x < W ? ((uint32_t)(x - aLn - org) | ((uint32_t)(aLn + aRn) << 16)) : (uint32_t)(x - org);              \
+        /* window [x - armL, x + armR) relative to the segment's first tile pixel (d_ca_cross_sum.cu:277-289); past the row: empty */ \
+        const int srel_ = x < W ? x - aLn - org : x - org, nn_ = x < W ? aLn + aRn : 0;                                    \
+        sn[tid] = (uint32_t)srel_ | ((uint32_t)nn_ << 16);                                                                 \
+        /* the sweep of the wave that owns these 16 pixels (a DPP row): first group, number of groups */                   \
+        int lo_ = nn_ ? (srel_ >> 2) : 0x7fffffff, hi_ = nn_ ? ((srel_ + nn_ + 3) >> 2) : -0x7fffffff;                     \
+        lo_ = min(lo_, row_ror_i<8>(lo_)); lo_ = min(lo_, row_ror_i<4>(lo_)); lo_ = min(lo_, row_ror_i<2>(lo_)); lo_ = min(lo_, row_ror_i<1>(lo_)); \
+        hi_ = max(hi_, row_ror_i<8>(hi_)); hi_ = max(hi_, row_ror_i<4>(hi_)); hi_ = max(hi_, row_ror_i<2>(hi_)); hi_ = max(hi_, row_ror_i<1>(hi_)); \
+        if ((tid & 15) == 0) sg[tid >> 4] = make_int2(lo_, hi_ - lo_);                                                     \
     }
     // first segment: the whole tile, NW pieces per round (shifted groups 4 NW seg0 + 4 NW r ..)
     for (int r0 = 0; r0 < NJ; r0 += NW) {
@@ -654,12 +696,10 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void stm_k_pq_hc(PQViews v, 
         if (X0 < W) { // uniform per wave
             const uint32_t e = sn[16 * w + dd]; // mask lanes: pixel dd of the wave
             const int srel = (int)(e & 0xffffu), nn = (int)(e >> 16);
-            const int G0r = wave_min_i(nn ? (srel >> 2) : 0x7fffffff);
-            const int Gend = wave_max_i(nn ? ((srel + nn + 3) >> 2) : -0x7fffffff);
-            const int n_it = STM_DBG(dbg, 1) ? 0 : Gend - G0r; // <= 0 when every window of the wave is empty
+            const int2 sgw = sg[w]; // first group of the wave's sweep, its length in groups (STM_HS_SN)
+            const int G0r = __builtin_amdgcn_readfirstlane(sgw.x);
+            const int n_it = STM_DBG(dbg, 1) ? 0 : __builtin_amdgcn_readfirstlane(sgw.y); // <= 0 when every window of the wave is empty
             f16v acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             if (n_it > 0) {
                 int gs = 4 * slot0 + G0r; // ring position (in groups) of the first group of the sweep
                 if (gs >= NG) gs -= NG;
@@ -683,16 +723,29 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void stm_k_pq_hc(PQViews v, 
     }
                 f4 ca, cb;
                 STM_HS_NEXT(ca)
-                int it = 0;
-                for (; it + 2 <= n_it; it += 2) {
-                    STM_HS_NEXT(cb)
-                    STM_HS_MFMA(ca)
-                    STM_HS_NEXT(ca) // on the last trip one group past the sweep: any ring slot, unused
-                    STM_HS_MFMA(cb)
+                STM_HS_NEXT(cb) // a sweep of one group: one group past it (any ring slot, unused)
+                {   // the first MFMA takes the constant 0 as its accumulator input: no register is cleared
+                    const float m = ((unsigned)t < (unsigned)nn) ? 1.0f : 0.0f;
+                    t += 4;
+                    const f16v z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc = STM_MFMA16(m, ca.x, z, 0);
+                    acc = STM_MFMA16(m, ca.y, acc, 1);
+                    acc = STM_MFMA16(m, ca.z, acc, 2);
+                    acc = STM_MFMA16(m, ca.w, acc, 3);
                 }
-                if (it < n_it) STM_HS_MFMA(ca)
+                int it = 1;
+                for (; it + 2 <= n_it; it += 2) {
+                    STM_HS_NEXT(ca)
+                    STM_HS_MFMA(cb)
+                    STM_HS_NEXT(cb) // on the last trip one group past the sweep: any ring slot, unused
+                    STM_HS_MFMA(ca)
+                }
+                if (it < n_it) STM_HS_MFMA(cb)
 #undef STM_HS_NEXT
 #undef STM_HS_MFMA
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             }
             // registers 4b..4b+3 of lane 16q + n = out[pixels X0 + 4q .. +3][hypothesis 16 b + n]
 #pragma unroll
@@ -823,23 +876,43 @@ __device__ __forceinline__ void v12t_begin(V12Sweep &S, const f4 *ring_l, int RQ
     S.mk = (ctab64 *)(r + 8);
     STM_V12_LOAD(S, S.A, RQ) // n_it == 0: any slot, any masks, unused
 }
+// the first MFMA of a sweep takes the constant 0 as its accumulator input (an inline operand: no register is cleared)
+#define STM_V12_MFMA0(Q)                                                                                           \
+    {                                                                                                              \
+        float a0 = STM_MASKF(Q.m0), a1 = STM_MASKF(Q.m1), a2 = STM_MASKF(Q.m2), a3 = STM_MASKF(Q.m3);              \
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));                                                 \
+        const f16v z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};           \
+        acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a0, Q.c.x, z, 0, 0, 0);                                         \
+        acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a1, Q.c.y, acc, 0, 0, 0);                                       \
+        acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a2, Q.c.z, acc, 0, 0, 0);                                       \
+        acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a3, Q.c.w, acc, 0, 0, 0);                                       \
+    }
 __device__ __forceinline__ f16v v12t_run(V12Sweep &S, int RQ)
 {
     f16v acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    V12Quad B;
-    int it = 0;
     const int n_it = S.n_it;
+    if (n_it == 0) { // a tile without a single window row (or a timing knob)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        return acc;
+    }
+    V12Quad B;
+    STM_V12_ARRIVED(S.A)
+    STM_V12_LOAD(S, B, RQ)
+    STM_V12_MFMA0(S.A)
+    int it = 1;
     for (; it + 2 <= n_it; it += 2) {
-        STM_V12_ARRIVED(S.A)
-        STM_V12_LOAD(S, B, RQ)
-        STM_V12_MFMA(S.A)
         STM_V12_ARRIVED(B)
-        STM_V12_LOAD(S, S.A, RQ) // on the last trip: one quad past the sweep (any ring slot; the record is a quad longer than the longest sweep)
+        STM_V12_LOAD(S, S.A, RQ)
+        STM_V12_MFMA(B)
+        STM_V12_ARRIVED(S.A)
+        STM_V12_LOAD(S, B, RQ) // on the last trip: one quad past the sweep (any ring slot; the record is a quad longer than the longest sweep)
+        STM_V12_MFMA(S.A)
+    }
+    if (it < n_it) {
+        STM_V12_ARRIVED(B)
         STM_V12_MFMA(B)
     }
-    if (it < n_it) STM_V12_MFMA(S.A)
     return acc;
 }
 
@@ -1030,7 +1103,7 @@ static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const 
     constexpr int NW = 8;
     const int HG = ((usd + 3) / 4 + 2) & ~1, NG = 4 * NW + 2 * HG; // halo groups: ceil(usd / 4) on either side of a segment + 1 for the read-ahead, rounded to an even number (the tile is filled four groups at a time)
     const int nseg = cdiv(W, 16 * NW), nblk = ((nseg * H * nviews + 7) / 8) * 8;
-    const size_t smem_h = (size_t)4 * NG * 256 + 16 * NW * 4;
+    const size_t smem_h = (size_t)4 * NG * 256 + 16 * NW * 4 + 8 * NW; // tile, window table, per-wave sweep ranges
     const int dbgh = timing_knobs();
     int pad = zd > D - 1 - zd ? zd : D - 1 - zd;
     pad = (pad < 0 ? 0 : pad) + 15; // + the padded hypotheses of the last chunk
@@ -1051,7 +1124,7 @@ static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const 
         constexpr int NWC = 12;
         const int NGc = 4 * NWC + 2 * HG;
         const size_t smem_c12 = (size_t)4 * NGc * 256 + 16 * NWC * 4 + (size_t)(4 * NGc * 4 + 4 * pad + 768 + 72) * 4;
-        const size_t smem_hc = (size_t)4 * NGc * 256 + 16 * NWC * 4 + (size_t)(2 * 16 * NWC + 2 * (16 * NWC + 2 * pad)) * 8 + (768 + 72) * 4;
+        const size_t smem_hc = (size_t)4 * NGc * 256 + 16 * NWC * 4 + 8 * NWC + (size_t)(2 * 16 * NWC + 2 * (16 * NWC + 2 * pad)) * 8 + (768 + 72) * 4;
         const int nsegc = cdiv(W, 16 * NWC);
         if (fuse_cost && NC <= 4 && NGc / 4 >= NWC && smem_hc <= 80 * 1024 && 16 * NWC + 2 * pad <= 64 * NWC && (agg_variant() / 1000) % 10 == 0) {
             // streaming row walk (one chunk set, the staged pixels fit one per thread); 2000: one block per segment as in round 2
