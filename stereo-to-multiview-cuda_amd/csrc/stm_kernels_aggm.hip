@@ -364,7 +364,6 @@ __global__ __launch_bounds__(64 * NW, (3 * NW) / 4) void stm_k_pq_hs(PQViews v, 
     const int NG = 4 * NW + 2 * HG, NJ = NG >> 2;
     f4 *tile = lds4; // [4 chunks][NJ slots][4 groups][16 hypotheses]
     uint32_t *sn = (uint32_t *)(tile + 4 * NG * 16);
-    int2 *sg = (int2 *)(sn + TX); // per wave tile: first group and length of its sweep
     const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lb = l >> 4, dd = l & 15;
     // block -> (view, row, part of the row)
@@ -399,12 +398,15 @@ __global__ __launch_bounds__(64 * NW, (3 * NW) / 4) void stm_k_pq_hs(PQViews v, 
         const int x = (S) * TX + tid, org = (S) * TX - 4 * HG;                                                             \
         /* window [x - armL, x + armR) relative to the segment's first tile pixel (d_ca_cross_sum.cu:277-289); past the row: empty */ \
         const int srel_ = x < W ? x - aLn - org : x - org, nn_ = x < W ? aLn + aRn : 0;                                    \
-        sn[tid] = (uint32_t)srel_ | ((uint32_t)nn_ << 16);                                                                 \
-        /* the sweep of the wave that owns these 16 pixels (a DPP row): first group, number of groups */                   \
+        /* the sweep of the wave that owns these 16 pixels (a DPP row): first group, number of groups -- computed once here */ \
+        /* instead of by every wave, and carried in the spare bits of the row's first two entries (a separate array would  */ \
+        /* cost the third block per CU: LDS is granted in 1280-byte granules and the tile + table fill 42 of them exactly) */ \
         int lo_ = nn_ ? (srel_ >> 2) : 0x7fffffff, hi_ = nn_ ? ((srel_ + nn_ + 3) >> 2) : -0x7fffffff;                     \
         lo_ = min(lo_, row_ror_i<8>(lo_)); lo_ = min(lo_, row_ror_i<4>(lo_)); lo_ = min(lo_, row_ror_i<2>(lo_)); lo_ = min(lo_, row_ror_i<1>(lo_)); \
         hi_ = max(hi_, row_ror_i<8>(hi_)); hi_ = max(hi_, row_ror_i<4>(hi_)); hi_ = max(hi_, row_ror_i<2>(hi_)); hi_ = max(hi_, row_ror_i<1>(hi_)); \
-        if ((tid & 15) == 0) sg[tid >> 4] = make_int2(lo_, hi_ - lo_);                                                     \
+        const int nit_ = max(hi_ - lo_, 0);                                                                                \
+        const int ex_ = (tid & 15) == 0 ? (nit_ ? lo_ : 0) : (tid & 15) == 1 ? nit_ : 0;                                   \
+        sn[tid] = (uint32_t)srel_ | ((uint32_t)nn_ << 12) | ((uint32_t)ex_ << 22); /* 12 + 10 + 10 bits */                 \
     }
     // first segment: the whole tile, pieces NW seg0 .. NW seg0 + NJ - 1 of every chunk, KP per wave and round
     {
@@ -438,10 +440,10 @@ __global__ __launch_bounds__(64 * NW, (3 * NW) / 4) void stm_k_pq_hs(PQViews v, 
         }
         if (X0 < W) { // uniform per wave
             const uint32_t e = sn[16 * w + dd]; // mask lanes: pixel dd of the wave
-            const int srel = (int)(e & 0xffffu), nn = (int)(e >> 16);
-            const int2 sgw = sg[w]; // first group of the wave's sweep, its length in groups (STM_HS_SN)
-            const int G0r = __builtin_amdgcn_readfirstlane(sgw.x);
-            const int n_it = STM_DBG(dbg, 1) ? 0 : STM_DBG(dbg, 2) ? 11 : __builtin_amdgcn_readfirstlane(sgw.y); // <= 0 when every window of the wave is empty
+            const int srel = (int)(e & 0xfffu), nn = (int)((e >> 12) & 0x3ffu);
+            // first group of the wave's sweep, its length in groups: the spare bits of the wave's first two entries (STM_HS_SN)
+            const int G0r = (int)((uint32_t)__builtin_amdgcn_readlane((int)e, 0) >> 22);
+            const int n_it = STM_DBG(dbg, 1) ? 0 : STM_DBG(dbg, 2) ? 11 : (int)((uint32_t)__builtin_amdgcn_readlane((int)e, 1) >> 22); // 0 when every window of the wave is empty
             f16v acc;
             if (n_it > 0) {
                 int gs = 4 * slot0 + G0r; // ring position (in groups) of the first group of the sweep
@@ -1103,7 +1105,7 @@ static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const 
     constexpr int NW = 8;
     const int HG = ((usd + 3) / 4 + 2) & ~1, NG = 4 * NW + 2 * HG; // halo groups: ceil(usd / 4) on either side of a segment + 1 for the read-ahead, rounded to an even number (the tile is filled four groups at a time)
     const int nseg = cdiv(W, 16 * NW), nblk = ((nseg * H * nviews + 7) / 8) * 8;
-    const size_t smem_h = (size_t)4 * NG * 256 + 16 * NW * 4 + 8 * NW; // tile, window table, per-wave sweep ranges
+    const size_t smem_h = (size_t)4 * NG * 256 + 16 * NW * 4; // tile, window table
     const int dbgh = timing_knobs();
     int pad = zd > D - 1 - zd ? zd : D - 1 - zd;
     pad = (pad < 0 ? 0 : pad) + 15; // + the padded hypotheses of the last chunk
