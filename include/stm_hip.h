@@ -68,8 +68,10 @@ int         stm_prof_read(const char *kernel, float *total_ms);
 /* aggregation variant of the frame pipeline (0 = default: matrix-pipe kernels, stm_kernels_aggm.hip); decimal digits, used by
  * the benchmark and the tools to A/B result-preserving variants in one process: 10000 = vector-ALU aggregation kernels
  * (stm_kernels_agg.hip; the low digits then select their tunables), 1000000 = separate initial-cost kernel instead of
- * computing the costs inside the first pass, 1000 = 128-pixel segments in the cost-computing pass, 10 = the last horizontal
- * pass as one block per segment instead of the streaming row walk.  Every accepted variant produces identical results.  The
+ * computing the costs inside the first pass, 1000 / 2000 = the cost-computing pass as one block per segment (128- / 192-pixel
+ * segments) instead of the row walk, 10 = the volume-reading horizontal passes as one block per segment instead of the row walk
+ * (20: only for num_disp > 64), 200 = view synthesis and interlacing as two kernels.  Every accepted variant produces identical
+ * results (tests/test_gpu_parity.py::test_device_frame_agg_variants).  The
  * digit N00000 (timing experiments that skip parts of kernels) is ignored here: it exists only in libstm_hip_timing.so,
  * a separate build of the same sources with -DSTM_TIMING (csrc/Makefile, `make timing`). */
 void        stm_set_agg_variant(int v);

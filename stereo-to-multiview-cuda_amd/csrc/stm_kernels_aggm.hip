@@ -376,15 +376,21 @@ __global__ __launch_bounds__(64 * NW, (3 * NW) / 4) void stm_k_pq_hs(PQViews v, 
     float *__restrict__ disp = view ? v.disp[1] : v.disp[0];
     const size_t row = (size_t)y * W;
     const uint32_t rowbytes = (uint32_t)G * 256u;
+    // D > 64: the row is walked once per chunk SET of 64 hypotheses; the WTA pass keeps each pixel's best (cost bits, d) of the
+    // sets before in `wb` (written and read back by the same lane, so no barrier is involved)
+    const int ncs = (NC + 3) >> 2;
+    uint2 *wb = (uint2 *)(sn + TX); // [pixels of this block's part of the row], only when WTA && ncs > 1
+    f4 st[KP];
+    int aLn = 0, aRn = 0;
+  for (int cs = 0; cs < ncs; ++cs) {
+    const int c0 = 4 * cs;
     // one row of each chunk; groups outside the row are out of range and read as zeros, chunks past the last are empty buffers
     __amdgpu_buffer_rsrc_t rin[4], rout[4];
 #pragma unroll
     for (int cl = 0; cl < 4; ++cl) {
-        rin[cl] = __builtin_amdgcn_make_buffer_rsrc((void *)(in + ((size_t)min(cl, NC - 1) * H + y) * G * 16), 0, cl < NC ? rowbytes : 0u, 0x00020000);
-        rout[cl] = __builtin_amdgcn_make_buffer_rsrc((void *)(out + ((size_t)min(cl, NC - 1) * H + y) * G * 16), 0, cl < NC ? rowbytes : 0u, 0x00020000);
+        rin[cl] = __builtin_amdgcn_make_buffer_rsrc((void *)(in + ((size_t)min(c0 + cl, NC - 1) * H + y) * G * 16), 0, c0 + cl < NC ? rowbytes : 0u, 0x00020000);
+        rout[cl] = __builtin_amdgcn_make_buffer_rsrc((void *)(out + ((size_t)min(c0 + cl, NC - 1) * H + y) * G * 16), 0, c0 + cl < NC ? rowbytes : 0u, 0x00020000);
     }
-    f4 st[KP];
-    int aLn = 0, aRn = 0;
     // piece (chunk cl, shifted piece index pa): groups 4 pa - HG .. + 3 of the row
 #define STM_HS_LOAD(K, CL, PA) st[K] = STM_DBG(dbg, 4) ? f4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin[CL], (4 * (PA) - HG) * 256 + l * 16, 0, 0));
 #define STM_HS_ARMS(S)                                                          \
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(64 * NW, (3 * NW) / 4) void stm_k_pq_hs(PQViews v, 
                 for (int i = 0; i < 4; ++i) { bc[i] = 3.402823466e+38f; bd[i] = 0; }
 #pragma unroll
                 for (int cl = 0; cl < 4; ++cl) {
-                    const int d = cl * 16 + dd;
+                    const int d = (c0 + cl) * 16 + dd;
                     if (d < D) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
@@ -531,6 +537,17 @@ __global__ __launch_bounds__(64 * NW, (3 * NW) / 4) void stm_k_pq_hs(PQViews v, 
                     cand = min(cand, row_ror_i<4>(cand));
                     cand = min(cand, row_ror_i<2>(cand));
                     cand = min(cand, row_ror_i<1>(cand));
+                    if (ncs > 1) { // uniform: combine with the chunk sets before (a later set wins only when strictly lower: ties to the lowest d)
+                        uint2 *slot = wb + (X0 - seg0 * TX + 4 * lb + i);
+                        if (dd == 0) {
+                            if (cs > 0) {
+                                const uint2 pv = *slot;
+                                if (!(m < (int)pv.x)) { m = (int)pv.x; cand = (int)pv.y; }
+                            }
+                            if (cs + 1 < ncs) *slot = make_uint2((uint32_t)m, (uint32_t)cand);
+                        }
+                        if (cs + 1 < ncs) continue; // uniform: the last set stores the disparity
+                    }
                     // lane dd == 0 of each pixel quad stores; the other lanes and pixels past the row are out of range
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (float)cand - (float)zd), rs,
                                                           dd == 0 ? (X0 + 4 * lb + i) * 4 : (int)0x7ffffff0, 0, 0);
@@ -550,6 +567,7 @@ __global__ __launch_bounds__(64 * NW, (3 * NW) / 4) void stm_k_pq_hs(PQViews v, 
         }
         __syncthreads();
     }
+  } // chunk sets
 #undef STM_HS_LOAD
 #undef STM_HS_ARMS
 #undef STM_HS_SN
@@ -589,14 +607,17 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void stm_k_pq_hc(PQViews v, 
     const int sgn = view ? -1 : 1;
     const size_t row = (size_t)y * W;
     const uint32_t rowbytes = (uint32_t)G * 256u;
-    __amdgpu_buffer_rsrc_t rout[4];
-#pragma unroll
-    for (int cl = 0; cl < 4; ++cl)
-        rout[cl] = __builtin_amdgcn_make_buffer_rsrc((void *)(out + ((size_t)min(cl, NC - 1) * H + y) * G * 16), 0, cl < NC ? rowbytes : 0u, 0x00020000);
     for (int i = tid; i < 768 + 65; i += NT) s_lut_ad[i] = lut_g[i];
     uint2 so = make_uint2(0, 0), sx = make_uint2(0, 0);
     int aLn = 0, aRn = 0;
     f4 cst[4];
+  const int ncs = (NC + 3) >> 2; // D > 64: the row is walked once per chunk set of 64 hypotheses
+  for (int cs = 0; cs < ncs; ++cs) {
+    const int c0 = 4 * cs;
+    __amdgpu_buffer_rsrc_t rout[4];
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl)
+        rout[cl] = __builtin_amdgcn_make_buffer_rsrc((void *)(out + ((size_t)min(c0 + cl, NC - 1) * H + y) * G * 16), 0, c0 + cl < NC ? rowbytes : 0u, 0x00020000);
     // pixels for the costs of the groups that start at shifted group A0 (group = A0 - HG): own image NEWPX pixels from
     // x0 = 4 (A0 - HG), other image the same +- pad, both clamped to the row (clamp-to-edge, d_ci_ad.cu:102)
 #define STM_HC_FETCH(A0)                                                                           \
@@ -628,8 +649,8 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void stm_k_pq_hc(PQViews v, 
         /* reads of a chunk are issued together and pixels outside the row / hypotheses >= D are zeroed by selects       */ \
         _Pragma("unroll") for (int cl = 0; cl < 4; ++cl) {                                                                \
             f4 val = {0.f, 0.f, 0.f, 0.f};                                                                                \
-            if (cl < NC) { /* uniform */                                                                                  \
-                const int d = cl * 16 + dd; /* < 16 NC <= D + 15: inside the staged range (pad) */                         \
+            if (c0 + cl < NC) { /* uniform */                                                                             \
+                const int d = (c0 + cl) * 16 + dd; /* < 16 NC <= D + 15: inside the staged range (pad) */                  \
                 const uint2 *oth = s_oth + (B) * SO + gi * 4 + sgn * (d - zd) + pad;                                      \
                 const uint2 q0 = oth[0], q1 = oth[1], q2 = oth[2], q3 = oth[3];                                           \
                 const float a0 = s_lut_ad[__builtin_amdgcn_sad_u8(o0.x, q0.x, 0u)], c0 = s_lut_c[hamdist_q1(o0.y, q0.y)]; \
@@ -770,6 +791,7 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void stm_k_pq_hc(PQViews v, 
         }
         __syncthreads();
     }
+  } // chunk sets
 #undef STM_HC_FETCH
 #undef STM_HC_STAGE
 #undef STM_HC_COSTS
@@ -1112,7 +1134,7 @@ static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const 
     const size_t smem_cost = smem_h + (size_t)(4 * NG * 4 + 4 * pad + 768 + 72) * 4;
     const bool fuse_cost = from_costs && (agg_variant() / 1000000) % 10 != 1; // 1: separate stm_k_pq_cost + volume-reading first pass
     const int spl = nseg > 24 ? cdiv(nseg, 16) : 1; // blocks per image row of the streaming passes
-    const bool streaming = NC <= 4 && NG / 4 >= NW && (agg_variant() / 10) % 10 != 1; // one chunk set; the ring is at least one segment long
+    const bool streaming = NG / 4 >= NW && (agg_variant() / 10) % 10 != 1 && (NC <= 4 || (agg_variant() / 10) % 10 != 2); // the ring is at least one segment long; 20: D > 64 on the block-per-segment kernels as before
     if (from_costs && !fuse_cost) {
         ProfScope p("pq_cost");
         const size_t smem = (size_t)(2 * PC_TX + 2 * (PC_TX + 2 * pad) + 768 + 72) * 4;
@@ -1128,11 +1150,17 @@ static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const 
         const size_t smem_c12 = (size_t)4 * NGc * 256 + 16 * NWC * 4 + (size_t)(4 * NGc * 4 + 4 * pad + 768 + 72) * 4;
         const size_t smem_hc = (size_t)4 * NGc * 256 + 16 * NWC * 4 + 8 * NWC + (size_t)(2 * 16 * NWC + 2 * (16 * NWC + 2 * pad)) * 8 + (768 + 72) * 4;
         const int nsegc = cdiv(W, 16 * NWC);
-        if (fuse_cost && NC <= 4 && NGc / 4 >= NWC && smem_hc <= 80 * 1024 && 16 * NWC + 2 * pad <= 64 * NWC && (agg_variant() / 1000) % 10 == 0) {
-            // streaming row walk (one chunk set, the staged pixels fit one per thread); 2000: one block per segment as in round 2
+        const size_t smem_hc8 = (size_t)4 * NG * 256 + 16 * NW * 4 + 8 * NW + (size_t)(2 * 16 * NW + 2 * (16 * NW + 2 * pad)) * 8 + (768 + 72) * 4;
+        const bool hc_ok = fuse_cost && (agg_variant() / 1000) % 10 == 0 && (NC <= 4 || (agg_variant() / 10) % 10 != 2);
+        if (hc_ok && smem_hc <= 80 * 1024 && 16 * NWC + 2 * pad <= 64 * NWC) {
+            // streaming row walk (the staged pixels fit one per thread); 2000: one block per segment as in round 2
             const int splc = nsegc > 24 ? cdiv(nsegc, 16) : 1;
             allow_lds_m((const void *)stm_k_pq_hc<NWC>, smem_hc);
             STM_LAUNCH((stm_k_pq_hc<NWC>), dim3(nviews * H * splc), dim3(64 * NWC), smem_hc, stream(), v, D, zd, H, W, G, NC, HG, nsegc, splc, lut, pad, dbgh);
+        } else if (hc_ok && smem_hc8 <= 80 * 1024 && 16 * NW + 2 * pad <= 64 * NW) {
+            // large D (more staged pixels): 128-pixel segments keep two blocks per CU
+            allow_lds_m((const void *)stm_k_pq_hc<NW>, smem_hc8);
+            STM_LAUNCH((stm_k_pq_hc<NW>), dim3(nviews * H * spl), dim3(64 * NW), smem_hc8, stream(), v, D, zd, H, W, G, NC, HG, nseg, spl, lut, pad, dbgh);
         } else if (fuse_cost && smem_c12 <= 80 * 1024 && (agg_variant() / 1000) % 10 != 1) { // 1000: 128-pixel segments as in the other passes
             const int nblkc = ((nsegc * H * nviews + 7) / 8) * 8;
             allow_lds_m((const void *)stm_k_pq_h<NWC, false, true>, smem_c12);
@@ -1174,8 +1202,12 @@ static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const 
             allow_lds_m((const void *)stm_k_pq_hs<NW, false>, smem_h);
             STM_LAUNCH((stm_k_pq_hs<NW, false>), dim3(nviews * H * spl), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, spl, dbgh);
         } else if (streaming) {
-            allow_lds_m((const void *)stm_k_pq_hs<NW, true>, smem_h);
-            STM_LAUNCH((stm_k_pq_hs<NW, true>), dim3(nviews * H * spl), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, spl, dbgh);
+            // D > 64: a pixel's best (cost, d) of the chunk sets before waits in LDS, 8 bytes per pixel of the block's part of the
+            // row: parts of at most 1920 pixels (15 KB; two blocks per CU)
+            const int splw = NC > 4 ? std::max(spl, cdiv(nseg * 16 * NW, 1920)) : spl;
+            const size_t smem_w = smem_h + (NC > 4 ? (size_t)cdiv(nseg, splw) * 16 * NW * 8 : 0);
+            allow_lds_m((const void *)stm_k_pq_hs<NW, true>, smem_w);
+            STM_LAUNCH((stm_k_pq_hs<NW, true>), dim3(nviews * H * splw), dim3(64 * NW), smem_w, stream(), v, D, zd, H, W, G, NC, HG, nseg, splw, dbgh);
         } else if (!wta) {
             allow_lds_m((const void *)stm_k_pq_h<NW, false, false>, smem_h);
             STM_LAUNCH((stm_k_pq_h<NW, false, false>), dim3(nblk), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, dbgh, lut, 0, nviews);

@@ -677,6 +677,34 @@ def test_device_frame_with_hslo_ragged_width(gpu_ready, orc, variant):
     assert np.array_equal(out.cpu().numpy(), want["interlaced"])
 
 
+@pytest.mark.parametrize("variant", [0, 10, 20, 200, 1000, 2000, 10000, 1000000])
+@pytest.mark.parametrize("shape", [(40, 150, 130, 64, 34, 17), (64, 331, 64, 32, 20, 10)])
+def test_device_frame_agg_variants(gpu_ready, orc, variant, shape):
+    """Every result-preserving kernel selection of stm_set_agg_variant (include/stm_hip.h) gives the oracle's frame: the row walks
+    (0; D = 130 takes three chunk sets through them, with the per-pixel WTA carry in LDS), the block-per-segment horizontal kernels
+    (10; 20 = for D > 64 only; 1000 / 2000 = the cost-computing pass), unfused view synthesis (200), the vector-ALU aggregation
+    (10000), the separate cost kernel (1000000)."""
+    import torch
+    import stm_amd
+    from stm_amd import device_api as dev, synth
+    H, W, D, zd, usd, lsd = shape
+    sbs, _ = synth.sbs_frame(H, W, D, zd)
+    p = dev.FrameParams(num_disp=D, zero_disp=zd, usd=usd, lsd=lsd)
+    dl = torch.zeros(H, W, dtype=torch.float32, device="cuda")
+    dr = torch.zeros_like(dl)
+    out = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+    stm_amd.lib().stm_set_agg_variant(variant)
+    try:
+        dev.d_adcensus_stm(torch.from_numpy(sbs).cuda(), dl, dr, out, p, stages=3)
+        torch.cuda.synchronize()
+    finally:
+        stm_amd.lib().stm_set_agg_variant(0)
+    want = orc.adcensus_stm(sbs, H, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd, p.usd,
+                            p.lsd, p.thresh_s, p.thresh_h)
+    assert np.array_equal(dl.cpu().numpy(), want["disp_l"]) and np.array_equal(dr.cpu().numpy(), want["disp_r"])
+    assert np.array_equal(out.cpu().numpy(), want["interlaced"])
+
+
 @pytest.mark.parametrize("stages", [1, 3])
 def test_device_frame_pipeline_with_hslo(gpu_ready, orc, stages):
     """BASELINE config 3 ordering: aggregation -> scanline optimisation -> WTA -> DCC/IRV/bilateral (stages | 0x100)."""
