@@ -124,6 +124,7 @@ struct IrvArgs {
 };
 constexpr uint32_t IV_ACCEPTED = 0x80000000u; // list entry: pixel accepted in the previous iteration
 constexpr uint32_t IV_DEAD = 0xFFFFFFFFu;     // list entry: nothing left to do
+constexpr uint32_t IV_LATER = 0x40000000u;    // list entry: the first iteration cannot accept this pixel (its region holds <= thresh_s reliable pixels)
 
 // vote code of one pixel: (int)disp + zero_disp is the histogram bin (d_dr_irv.cu:200-201)
 constexpr uint32_t IV_NOVOTE = 0xFFFFu;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64 * ICP_SEG) void stm_k_irv_colprefix(const uint16
 // appended in raster order with ONE global atomic (the counter is a single address: per-wave atomics made this
 // kernel atomic-bound)
 constexpr int IC_T = 1024;
-__global__ __launch_bounds__(IC_T) void stm_k_irv_compact(IrvArgs a, uint32_t HW, int zd, int nb, int H, int W, int usd, float thresh_h)
+__global__ __launch_bounds__(IC_T) void stm_k_irv_compact(IrvArgs a, uint32_t HW, int zd, int nb, int H, int W, int usd, float thresh_h, int thresh_s)
 {
     __shared__ int s_tot[IC_T / 64];
     __shared__ int s_base;
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(IC_T) void stm_k_irv_compact(IrvArgs a, uint32_t HW
         }
     }
     const uint32_t *__restrict__ vp = a.vp[v];
+    uint32_t later = 0; // bit j: pixel p + j cannot be accepted in the first iteration (S0 <= thresh_s, d_dr_irv.cu:35): its vote is skipped there
     if (vp != nullptr && w != 0) { // outliers that can never be accepted are not listed (see stm_k_irv_rowcount)
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j)
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(IC_T) void stm_k_irv_compact(IrvArgs a, uint32_t HW
                 const int s0 = (int)(vp[(size_t)(gy + cd + 1) * W + gx] - vp[(size_t)(gy - cu) * W + gx]);
                 const int nmax = max(nb - 1, (int)disp[q] + zd);
                 if (s0 > 0 && !((float)nmax / (float)s0 > thresh_h)) w &= ~(0xffu << (8 * j));
+                else if (s0 <= thresh_s) later |= 1u << j;
             }
     }
     const int c = ((w & 0xff) != 0) + ((w & 0xff00) != 0) + ((w & 0xff0000) != 0) + ((w & 0xff000000u) != 0);
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(IC_T) void stm_k_irv_compact(IrvArgs a, uint32_t HW
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j)
         if ((w >> (8 * j)) & 0xff) {
-            if ((uint32_t)k < HW) list[k] = p + j; // the list holds HW entries: a counter that was not cleared can never write past it
+            if ((uint32_t)k < HW) list[k] = (p + j) | ((later >> j) & 1u ? IV_LATER : 0u); // the list holds HW entries: a counter that was not cleared can never write past it
             ++k;
         }
 }
@@ -397,7 +400,8 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
     for (; i < n; i += stride) {
         const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)entry_next);
         entry_next = i + stride < n ? list[i + stride] : IV_DEAD; // in flight while this outlier is processed
-        if ((entry & ~IV_ACCEPTED) >= (uint32_t)(H * W)) continue; // IV_DEAD, or not a pixel of this frame (stale memory behind a wrong counter)
+        if ((entry & ~(IV_ACCEPTED | IV_LATER)) >= (uint32_t)(H * W)) continue; // IV_DEAD, or not a pixel of this frame (stale memory behind a wrong counter)
+        if ((entry & IV_LATER) && it == 0) continue; // S <= thresh_s in this iteration: rejected whatever the votes (the flag is ignored afterwards)
         if (entry & IV_ACCEPTED) { // accepted by the previous launch: bring this launch's write plane up to date
             if (lane == 0) {
                 const uint32_t q = entry & ~IV_ACCEPTED;
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
             }
             continue;
         }
-        const int p = (int)entry;
+        const int p = (int)(entry & ~IV_LATER);
         const int gy = p / W, gx = p - gy * W;
         int cu = a.aU[v][p], cd = a.aD[v][p];
         const float own = disp[p]; // needed only for the default vote at the very end: issued here so its latency is hidden
@@ -549,8 +553,8 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
     a.vp[0] = vp[0];
     a.vp[1] = nviews == 2 ? vp[1] : vp[0];
     if (rounds == 0) return; // nothing observable happens (a host-flavour vote without an apply only fills scratch)
-    if (HW >= IV_ACCEPTED) {
-        fail("dr_irv: more than 2^31 - 1 pixels", "num_rows * num_cols", __FILE__, __LINE__);
+    if (HW >= IV_LATER) {
+        fail("dr_irv: more than 2^30 - 1 pixels", "num_rows * num_cols", __FILE__, __LINE__);
         return;
     }
     ProfScope p("irv");
@@ -564,7 +568,7 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
         STM_CHECK_LAUNCH();
     }
     STM_LAUNCH(stm_k_irv_compact, dim3((unsigned)((HW + 4 * IC_T - 1) / (4 * IC_T)), nviews), dim3(IC_T), 0, stream(), a, (uint32_t)HW, zd,
-                       nb, H, W, usd, thresh_h);
+                       nb, H, W, usd, thresh_h, thresh_s);
     STM_CHECK_LAUNCH();
     const size_t smem = (size_t)(nb + 1 + 64) * 16 * IV_WAVES; // per wave: four copies of (other, nb bins), one slot per lane
     // Several times more waves than the chip holds (1080p: 8100 blocks of 2 waves per view for 8192 wave slots): the waves walk
