@@ -149,11 +149,18 @@ def main():
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     stm_amd.lib()  # raises if the HIP library is missing: there is no fallback path
-    torch.cuda.set_device(local_rank)
+    # STM_BENCH_REHEARSAL=gloo: the N-rank code path on a ONE-GPU box (RCCL refuses two ranks on one device): every rank uses cuda:0,
+    # the process group is gloo, the batch moves through host tensors.  It checks that the multi-rank flow runs end to end; its
+    # line is marked invalid and is not a measurement.
+    rehearsal = os.environ.get("STM_BENCH_REHEARSAL", "") == "gloo" and world > 1
+    torch.cuda.set_device(0 if rehearsal else local_rank)
     rccl_world = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         rccl_world = dist.get_world_size()
 
     H, W, D = args.height, args.width, args.disp
@@ -165,7 +172,8 @@ def main():
     per_rank = len(sharding.shard_indices(B, rank, world))
 
     # ---- input batch: generated on rank 0 -------------------------------------------------------------
-    batch = torch.zeros(B, H, 2 * W, 3, dtype=torch.uint8, device="cuda") if (rank == 0 or not moving) else None
+    move_dev = "cpu" if rehearsal else "cuda"  # where the scattered / gathered tensors live
+    batch = torch.zeros(B, H, 2 * W, 3, dtype=torch.uint8, device=move_dev if moving else "cuda") if (rank == 0 or not moving) else None
     sbs_host = None
     if rank == 0:
         frames = []
@@ -187,9 +195,13 @@ def main():
     if moving:
         pipe = sharding.FrameBatchPipeline(B, (H, 2 * W, 3), torch.uint8,
                                            {"disp_l": ((H, W), torch.float32), "disp_r": ((H, W), torch.float32), "interlaced": ((H, W, 3), torch.uint8)},
-                                           "cuda", rank, world)
+                                           move_dev, rank, world)
 
     def run_frame(fr, outs):
+        if rehearsal:  # host tensors in and out (gloo): compute on the GPU through the resident buffers
+            dev.d_adcensus_stm(fr.cuda(), dl, dr, out, p, stages=args.stages)
+            outs["disp_l"].copy_(dl); outs["disp_r"].copy_(dr); outs["interlaced"].copy_(out)
+            return
         dev.d_adcensus_stm(fr, outs["disp_l"], outs["disp_r"], outs["interlaced"], p, stages=args.stages)
 
     def steps(n):
@@ -216,7 +228,7 @@ def main():
         dt = time.perf_counter() - t0
         if profile:
             dev.prof_enable(False)
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
@@ -335,6 +347,8 @@ def main():
             rc = real_content(torch, dev, synth, p, H, W, D, zd, args.stages, read_all)
             if rc:
                 res["real_content"] = rc
+        if rehearsal:
+            res["invalid"] = "STM_BENCH_REHEARSAL=gloo: %d ranks on one GPU over gloo and host tensors -- a dry run of the multi-rank flow, not a measurement" % world
         bad = 0
         if not args.no_cpu_baseline and world == 1:
             def run_gpu(part, rows):
