@@ -69,11 +69,24 @@ __global__ __launch_bounds__(256) void stm_k_cross_arms(ArmsArgs a, uint32_t tg_
     const int p = y * W + x;
     const uint32_t *__restrict__ img = a.img[v];
     const uint32_t anchor = img[p];
-    // the four arms of a pixel walk together: four independent loads per step, one exit test for all of them
-    const char *base = (const char *)img;
-    const int pix4 = 4 * p;
-    const int st4[4] = {-4 * W, 4 * W, -4, 4};
+    // the four arms of a pixel walk together: four independent loads per step, one exit test for all of them.
+    // Addresses: a block is one image row, so the row an up / down step reads is wave-uniform -- a scalar base + the lane's
+    // constant byte offset, no vector arithmetic; left / right steps clamp the lane's offset into the row (two instructions).
+    // Steps past an arm's border re-read the border pixel; their verdict cannot shorten the arm (it starts at kmax).
+    const char *rowbase = (const char *)img + (size_t)y * W * 4;
+    const uint32_t x4 = 4u * (uint32_t)x;
+    const int xmax4 = 4 * (W - 1);
+    const size_t rowb = (size_t)W * 4;
     const int kmax[4] = {min(usd, y), min(usd, H - 1 - y), min(usd, x), min(usd, W - 1 - x)};
+#define STM_ARM_LOADS(K)                                                                                         \
+    {                                                                                                            \
+        uint32_t xo = x4;                                                                                        \
+        asm volatile("" : "+v"(xo)); /* keeps (row base + x) from being folded into one 64-bit vector address: the row base stays scalar */ \
+        c[0] = *(const uint32_t *)(rowbase - (size_t)min(K, kmax[0]) * rowb + (size_t)xo);                        \
+        c[1] = *(const uint32_t *)(rowbase + (size_t)min(K, kmax[1]) * rowb + (size_t)xo);                        \
+        c[2] = *(const uint32_t *)(rowbase + (size_t)(uint32_t)max((int)x4 - 4 * (K), 0));                        \
+        c[3] = *(const uint32_t *)(rowbase + (size_t)(uint32_t)min((int)x4 + 4 * (K), xmax4));                    \
+    }
     int arm[4] = {kmax[0], kmax[1], kmax[2], kmax[3]};
     const uint32_t anchor_n = anchor + tg_near;
     uint32_t prev[4] = {anchor, anchor, anchor, anchor}, prev_t[4] = {anchor_n, anchor_n, anchor_n, anchor_n};
@@ -85,8 +98,7 @@ __global__ __launch_bounds__(256) void stm_k_cross_arms(ArmsArgs a, uint32_t tg_
         for (int j = 0; j < 2; ++j) {
             if (k <= knear) { // uniform
                 uint32_t c[4];
-#pragma unroll
-                for (int d = 0; d < 4; ++d) c[d] = *(const uint32_t *)(base + (pix4 + __mul24(min(k, kmax[d]), st4[d])));
+                STM_ARM_LOADS(k)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const uint32_t c_t = c[d] + tg_near;
@@ -107,8 +119,7 @@ __global__ __launch_bounds__(256) void stm_k_cross_arms(ArmsArgs a, uint32_t tg_
         for (int j = 0; j < 2; ++j) {
             if (k <= usd) {
                 uint32_t c[4];
-#pragma unroll
-                for (int d = 0; d < 4; ++d) c[d] = *(const uint32_t *)(base + (pix4 + __mul24(min(k, kmax[d]), st4[d])));
+                STM_ARM_LOADS(k)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const uint32_t ok = (c[d] + far_lo) & (far_hi - c[d]) & W10_GUARD;
@@ -118,6 +129,7 @@ __global__ __launch_bounds__(256) void stm_k_cross_arms(ArmsArgs a, uint32_t tg_
             }
         }
     }
+#undef STM_ARM_LOADS
     a.up[v][p] = (u8)arm[0];
     a.down[v][p] = (u8)arm[1];
     a.left[v][p] = (u8)arm[2];
