@@ -705,6 +705,25 @@ def test_device_frame_agg_variants(gpu_ready, orc, variant, shape):
     assert np.array_equal(out.cpu().numpy(), want["interlaced"])
 
 
+def test_device_frame_very_large_disparity_range(gpu_ready, orc):
+    """num_disp = 400 (25 chunks, 7 chunk sets; the cost-computing row walk cannot stage 2 x 215 pixels of padding per thread and
+    hands the first pass to the block-per-segment kernel; the other passes walk the row once per chunk set)."""
+    import torch
+    from stm_amd import device_api as dev, synth
+    H, W, D, zd = 24, 150, 400, 200
+    sbs, _ = synth.sbs_frame(H, W, D, zd)
+    p = dev.FrameParams(num_disp=D, zero_disp=zd, usd=9, lsd=4)
+    dl = torch.zeros(H, W, dtype=torch.float32, device="cuda")
+    dr = torch.zeros_like(dl)
+    out = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+    dev.d_adcensus_stm(torch.from_numpy(sbs).cuda(), dl, dr, out, p, stages=3)
+    torch.cuda.synchronize()
+    want = orc.adcensus_stm(sbs, H, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd, p.usd,
+                            p.lsd, p.thresh_s, p.thresh_h)
+    assert np.array_equal(dl.cpu().numpy(), want["disp_l"]) and np.array_equal(dr.cpu().numpy(), want["disp_r"])
+    assert np.array_equal(out.cpu().numpy(), want["interlaced"])
+
+
 @pytest.mark.parametrize("stages", [1, 3])
 def test_device_frame_pipeline_with_hslo(gpu_ready, orc, stages):
     """BASELINE config 3 ordering: aggregation -> scanline optimisation -> WTA -> DCC/IRV/bilateral (stages | 0x100)."""
