@@ -444,6 +444,32 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
                 roff = 2u * (uint32_t)(q - cl);
             }
             const int jend = min(nrows - jb, 64); // wave-uniform
+            if (__ballot(rw > 32) == 0) {
+                // every row segment of this chunk fits half a wave (the common case on textured content): TWO region rows per step,
+                // lanes 0-31 on row j, lanes 32-63 on row j + 1; each lane fetches its row's offset and width from the lane that
+                // holds them (ds_bpermute: the LDS crossbar, no memory access, no scalar round trip)
+                const int half4 = (lane >> 5) * 4;
+                const uint32_t l2 = 2u * (uint32_t)(lane & 31);
+                const int lw = lane & 31;
+                for (int j0 = 0; j0 < jend; j0 += 2 * IV_U) { // j0 + 2 u + 1 <= 63: no wrap of the lane index (64 is a multiple of 2 IV_U)
+                    uint32_t cdv[IV_U];
+                    int wv[IV_U];
+                    const int sel = half4 + 4 * j0;
+#pragma unroll
+                    for (int u = 0; u < IV_U; ++u) { // rows past jend: their lanes hold offset 0 / width 0
+                        const uint32_t so = (uint32_t)__builtin_amdgcn_ds_bpermute(sel + 8 * u, (int)roff);
+                        wv[u] = __builtin_amdgcn_ds_bpermute(sel + 8 * u, rw);
+                        cdv[u] = *(const uint16_t *)((const char *)code_pl + (so + l2));
+                    }
+#pragma unroll
+                    for (int u = 0; u < IV_U; ++u) {
+                        const uint32_t c = lw < wv[u] ? cdv[u] : IV_NOVOTE;
+                        const uint32_t slot = min(c, nv_slot);
+                        atomicAdd(irv_lds + ((slot * 16u + sub_addr) >> 2), 1u);
+                    }
+                }
+                continue; // next chunk of rows
+            }
             for (int j0 = 0; j0 < jend; j0 += IV_U) {
                 uint32_t cdv[IV_U];
 #pragma unroll
