@@ -156,33 +156,42 @@ __global__ __launch_bounds__(256) void stm_k_irv_clear(int *__restrict__ words, 
 //   stm_k_irv_rowcount:  cnt[y][x] = reliable pixels of row y inside the row segment of pixel (y, x)  (row prefix sums in LDS);
 //   stm_k_irv_colprefix: vp[y][x]  = cnt[0][x] + .. + cnt[y - 1][x];  S0(y, x) = vp[y + armD + 1][x] - vp[y - armU][x].
 // The compaction kernel then lists only the outliers that can still be accepted.
-__global__ __launch_bounds__(64) void stm_k_irv_rowcount(IrvArgs a, uint16_t *__restrict__ cnt0, uint16_t *__restrict__ cnt1, int H, int W)
+constexpr int IRC_W = 4; // waves per image row: each takes a quarter of the row (a one-wave block walked the row in eight dependent trips)
+__global__ __launch_bounds__(64 * IRC_W) void stm_k_irv_rowcount(IrvArgs a, uint16_t *__restrict__ cnt0, uint16_t *__restrict__ cnt1, int H, int W)
 {
     extern __shared__ uint32_t rp[]; // rp[x] = reliable pixels of this row in columns < x, x in [0, W]
-    const int v = blockIdx.y, y = blockIdx.x, lane = threadIdx.x;
+    __shared__ int s_tot[IRC_W];
+    const int v = blockIdx.y, y = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const u8 *__restrict__ outl = a.outl[v];
     const u8 *__restrict__ aL = a.aL[v], *__restrict__ aR = a.aR[v];
     uint16_t *__restrict__ cnt = (v ? cnt1 : cnt0) + (size_t)y * W;
     const size_t row = (size_t)y * W;
+    const int Wq = (((W + IRC_W - 1) / IRC_W) + 63) & ~63; // columns per wave, a multiple of 64
+    const int xb = wv * Wq, xe = min(W, xb + Wq);
     int carry = 0;
-    if (lane == 0) rp[0] = 0;
-    for (int x0 = 0; x0 < W; x0 += 256) { // four chunks of 64 per trip: their loads are in flight together
+    if (threadIdx.x == 0) rp[0] = 0;
+    for (int x0 = xb; x0 < xe; x0 += 256) { // four chunks of 64 per trip: their loads are in flight together
         u8 o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = outl[row + min(x0 + 64 * k + lane, W - 1)];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { // prefix inside a chunk = population count of the ballot below the lane (v_mbcnt)
             const int x = x0 + 64 * k + lane;
-            const bool r = x < W && o[k] == 0;
+            const bool r = x < xe && o[k] == 0;
             const unsigned long long m = __ballot(r);
             const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (x < W) rp[x + 1] = (uint32_t)(carry + below + (r ? 1 : 0));
+            if (x < xe) rp[x + 1] = (uint32_t)(carry + below + (r ? 1 : 0)); // relative to the wave's first column
             carry += __popcll(m);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int x0 = 0; x0 < W; x0 += 256) { // the row segment of the vote kernel: [x - armL, x + armR] clamped into the row
+    if (lane == 0) s_tot[wv] = carry;
+    __syncthreads();
+    int off = 0; // reliable pixels left of this wave's part
+    for (int q = 0; q < wv; ++q) off += s_tot[q];
+    if (off)
+        for (int x = xb + lane; x < xe; x += 64) rp[x + 1] += (uint32_t)off;
+    __syncthreads();
+    for (int x0 = xb; x0 < xe; x0 += 256) { // the row segment of the vote kernel: [x - armL, x + armR] clamped into the row
         int al[4], ar[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(64) void stm_k_irv_rowcount(IrvArgs a, uint16_t *__
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int x = x0 + 64 * k + lane;
-            if (x < W) {
+            if (x < xe) {
                 const int cl = min(al[k], x);
                 const int w = max(min(cl + ar[k] + 1, W - (x - cl)), 0);
                 cnt[x] = (uint16_t)(rp[x - cl + w] - rp[x - cl]);
@@ -587,7 +596,7 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
     STM_LAUNCH(stm_k_irv_clear, dim3((unsigned)cdiv((int)nwords, 256)), dim3(256), 0, stream(), counts, (int)nwords);
     STM_CHECK_LAUNCH();
     if (prune) {
-        STM_LAUNCH(stm_k_irv_rowcount, dim3(H, nviews), dim3(64), (size_t)(W + 1) * 4, stream(), a, cnt[0], nviews == 2 ? cnt[1] : cnt[0], H, W);
+        STM_LAUNCH(stm_k_irv_rowcount, dim3(H, nviews), dim3(64 * IRC_W), (size_t)(W + 1) * 4, stream(), a, cnt[0], nviews == 2 ? cnt[1] : cnt[0], H, W);
         STM_CHECK_LAUNCH();
         STM_LAUNCH(stm_k_irv_colprefix, dim3(cdiv(W, 64), nviews), dim3(64 * ICP_SEG), 0, stream(), cnt[0], nviews == 2 ? cnt[1] : cnt[0], vp[0],
                    nviews == 2 ? vp[1] : vp[0], H, W);
