@@ -206,6 +206,11 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
                        int D, int zd, int H, int W, int usd, bool keep_volume = false);
 // ca_cross / d_ca_cross of one volume in the caller's layout on the matrix-pipe kernels; `out` may be `in`
 void launch_aggm_stage(Vol in, Vol out, const u8 *armU, const u8 *armD, const u8 *armL, const u8 *armR, int D, int H, int W, int usd);
+// both vertical passes with a strip's rows in registers (stm_kernels_aggv.hip); `tab` / `rec`: the table of stm_k_vwin_table
+bool aggv_supports(int usd);
+int aggv_table_top();
+int aggv_table_rec();
+void launch_pq_v12r(PQViews &v, int nviews, const uint32_t *tab, int rec, int H, int W, int G, int NC);
 void launch_to_pq(Vol in, float *pq, int D, int H, int W);         // stm_kernels_hslo.hip
 void launch_from_pq(const float *pq, Vol out, int D, int H, int W); // stm_kernels_aggm.hip
 // HSLO (stm_kernels_hslo.hip)

@@ -825,7 +825,10 @@ __global__ __launch_bounds__(64 * NW, (2 * NW) / 4) void stm_k_pq_hc(PQViews v, 
 // Table record of tile (view, u = y / 16, g), `rec` dwords: [0] K0 (first row of the sweep, multiple of 4), [1] n_it
 // (sweep length in quads), [8 + 8 it ..] the four 64-bit masks of quad it: bit 16 b + i = row 16 u + i of column 4 g + b has
 // row K0 + 4 it + j in its window [y - armU, y + armD)  (d_ca_cross_sum.cu:172-173,189-194).
-__global__ __launch_bounds__(256) void stm_k_vwin_table(PQViews v, uint32_t *__restrict__ tab, int rec, int H, int W, int G, int nT)
+// top >= 0: the STATIC layout of stm_k_pq_v12r (stm_kernels_aggv.hip) -- [0] q0 = (K0 - (16 u - top)) / 4, the sweep's first quad
+// inside the tile's range [16 u - top, ..), [1] n_it, and the masks of range quad J at [8 + 8 J ..] (only the sweep's own quads
+// are written; nothing reads the others' contents for a result).
+__global__ __launch_bounds__(256) void stm_k_vwin_table(PQViews v, uint32_t *__restrict__ tab, int rec, int H, int W, int G, int nT, int top)
 {
     const int l = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6), u = blockIdx.y, view = blockIdx.z;
     if (g >= G) return; // uniform per wave
@@ -841,8 +844,9 @@ __global__ __launch_bounds__(256) void stm_k_vwin_table(PQViews v, uint32_t *__r
     const int hi = wave_max_i(nn ? s0 + nn : -0x7fffffff);
     const int K0 = hi > lo ? (lo & ~3) : 0, n_it = hi > lo ? (hi - K0 + 3) >> 2 : 0;
     uint32_t *dst = tab + ((size_t)(view * nT + u) * G + g) * rec;
-    if (l < 8) dst[l] = l == 0 ? (uint32_t)K0 : l == 1 ? (uint32_t)n_it : 0u;
-    unsigned long long *mk = (unsigned long long *)(dst + 8);
+    const int q0 = top >= 0 && n_it ? (K0 - (16 * u - top)) >> 2 : 0;
+    if (l < 8) dst[l] = l == 0 ? (uint32_t)(top >= 0 ? q0 : K0) : l == 1 ? (uint32_t)n_it : 0u;
+    unsigned long long *mk = (unsigned long long *)(dst + 8) + 4 * q0;
     const int steps = 4 * n_it;
     for (int base = 0; base < steps; base += 64) {
         unsigned long long mine = 0;
@@ -1181,20 +1185,25 @@ static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const 
         // fused vertical kernel; the window table is built once per call for all views
         constexpr int NTP = 3, TS = 16 * NTP; // 2 and 4 tiles per pass and step: 0.729 ms each against 0.679
         const int UQ = (usd + 3) & ~3, nT = (H + 15) / 16;
-        const int rec = 8 + 8 * ((2 * usd + 21) / 4 + 2); // header + the longest sweep + one quad of read-ahead
+        const bool regs = aggv_supports(usd) && (agg_variant() / 10000000) % 10 != 1; // round 4: a strip's rows in registers (stm_kernels_aggv.hip); 10000000: the LDS-ring kernel
+        const int rec = regs ? aggv_table_rec() : 8 + 8 * ((2 * usd + 21) / 4 + 2); // header + the longest sweep + one quad of read-ahead
         const int LAG = (UQ + TS - 1) / TS + 1;
         const int RQ1 = (TS + 2 * UQ) / 4, RQ2 = (TS * (LAG + 1) + UQ) / 4;
         uint32_t *tab = Workspace::get<uint32_t>((size_t)nviews * nT * G * rec);
         {
             ProfScope p("pq_vtab");
-            STM_LAUNCH(stm_k_vwin_table, dim3(cdiv(G, 4), nT, nviews), dim3(256), 0, stream(), v, tab, rec, H, W, G, nT);
+            STM_LAUNCH(stm_k_vwin_table, dim3(cdiv(G, 4), nT, nviews), dim3(256), 0, stream(), v, tab, rec, H, W, G, nT, regs ? aggv_table_top() : -1);
             STM_CHECK_LAUNCH();
         }
         ProfScope p("pq_v12");
-        const size_t smem = (size_t)(RQ1 + RQ2) * 1024;
-        allow_lds_m((const void *)stm_k_pq_v12t<NTP>, smem);
-        STM_LAUNCH(stm_k_pq_v12t<NTP>, dim3(G, NC, nviews), dim3(128 * NTP), smem, stream(), v, tab, rec, H, W, G, NC, UQ, RQ1, RQ2, LAG, dbgh);
-        STM_CHECK_LAUNCH();
+        if (regs) {
+            launch_pq_v12r(v, nviews, tab, rec, H, W, G, NC);
+        } else {
+            const size_t smem = (size_t)(RQ1 + RQ2) * 1024;
+            allow_lds_m((const void *)stm_k_pq_v12t<NTP>, smem);
+            STM_LAUNCH(stm_k_pq_v12t<NTP>, dim3(G, NC, nviews), dim3(128 * NTP), smem, stream(), v, tab, rec, H, W, G, NC, UQ, RQ1, RQ2, LAG, dbgh);
+            STM_CHECK_LAUNCH();
+        }
     }
     {
         ProfScope p("pq_hw");
