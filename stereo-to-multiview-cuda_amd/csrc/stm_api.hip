@@ -127,12 +127,13 @@ void core_ci(const u8 *d_img_l, const u8 *d_img_r, Vol cl, Vol cr, uint32_t *pk_
 }
 
 // aggregation H, V, V, H (d_ca_cross.cu:255-270 minus the transposes); result ends in `cost`
+// scratch.base == nullptr: carved here when the vector-ALU kernels run (a plane slab of D * H * W floats)
+static bool agg_on_matrix_pipe(int usd, int H, int W) { return (agg_variant() / 10000) % 10 != 1 && aggm_supports(usd, H, W); }
 void core_agg(Vol cost, Vol scratch, const Arms &a, int D, int H, int W, int usd)
 {
-    if ((agg_variant() / 10000) % 10 != 1 && aggm_supports(usd, H, W)) { // the frame pipeline's matrix-pipe kernels (round 3)
-        launch_aggm_stage(cost, cost, a.up, a.down, a.left, a.right, D, H, W, usd);
-        return;
-    }
+    // the frame pipeline's matrix-pipe kernels (round 3) -- unless the caller's volume holds infinities, NaNs or denormals
+    if (agg_on_matrix_pipe(usd, H, W) && launch_aggm_stage(cost, cost, a.up, a.down, a.left, a.right, D, H, W, usd)) return;
+    if (!scratch.base && !scratch.tab) scratch = vol_slab(Workspace::get<float>((size_t)D * H * W), (size_t)H * W);
     launch_agg_h(cost, scratch, a.left, a.right, D, H, W);
     launch_agg_v(scratch, cost, a.up, a.down, D, H, W, usd);
     launch_agg_v(cost, scratch, a.up, a.down, D, H, W, usd);
@@ -240,7 +241,8 @@ void stm_d_ca_cross(unsigned char *d_img, float **d_cost, float **d_acost, float
                                 {"elem_sz", elem_sz, 3}}))
         return;
     size_t HW = (size_t)num_rows * num_cols;
-    Workspace::begin(2 * HW * 4 + 8192);
+    // (what launch_aggm_stage carves is part of the hint: no allocation happens inside the call once the slab has this size)
+    Workspace::begin(12 * HW + 8192 + (agg_on_matrix_pipe(usd, num_rows, num_cols) ? aggm_stage_bytes(num_disp, num_rows, num_cols, usd) : 0));
     for (int d = 0; d < num_disp; ++d) h_acost[d] = d_acost_memory + (size_t)d * HW; // d_ca_cross.cu:207-210
     STM_CHECK(hipMemcpyAsync(d_acost, h_acost, sizeof(float *) * num_disp, hipMemcpyHostToDevice, stream()));
     Arms a = arms_from_table(d_cross);
@@ -257,10 +259,11 @@ void stm_ca_cross(unsigned char *img, unsigned char **cross, float **cost, float
                               {"elem_sz", elem_sz, 3}}))
         return;
     size_t HW = (size_t)num_rows * num_cols, V = HW * num_disp;
-    Workspace::begin(2 * V * 4 + HW * elem_sz + 12 * HW + 16384);
+    const bool mp = agg_on_matrix_pipe(usd, num_rows, num_cols);
+    Workspace::begin(V * 4 + HW * elem_sz + 12 * HW + 16384 + (mp ? aggm_stage_bytes(num_disp, num_rows, num_cols, usd) : V * 4));
     u8 *dimg = up(img, HW * elem_sz);
     float *c = up_planes(cost, num_disp, HW);
-    float *s = Workspace::get<float>(V);
+    float *s = mp ? nullptr : Workspace::get<float>(V); // the vector-ALU kernels' scratch volume (carved late if they run as the fallback)
     Arms a = carve_arms(HW);
     uint32_t *pk = Workspace::get<uint32_t>(HW);
     launch_pack_bgrx(dimg, pk, num_rows, num_cols, elem_sz);

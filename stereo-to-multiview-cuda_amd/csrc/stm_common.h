@@ -32,6 +32,9 @@ void release_host_frame_bufs(); // stm_api.hip: the calling thread's staging buf
     } while (0)
 
 hipStream_t stream();
+// One word per device, allocated on first use and never freed (so a captured graph can keep its address), zero unless a kernel
+// clamped something that cannot happen (see IrvArgs::diag).  stm_last_error() reads and clears it.
+uint32_t *device_diag();
 
 // ---- grow-only device workspace, bump-allocated per top-level call -----------------
 // The reference hipMalloc/hipFree's ~35 buffers per frame (d_io.cu:43-235); here one
@@ -204,14 +207,17 @@ bool aggm_supports(int usd, int H, int W);
 void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, const float *lut, float *const *vol_a, float *const *vol_b,
                        const u8 *const *armU, const u8 *const *armD, const u8 *const *armL, const u8 *const *armR, float *const *disp,
                        int D, int zd, int H, int W, int usd, bool keep_volume = false);
-// ca_cross / d_ca_cross of one volume in the caller's layout on the matrix-pipe kernels; `out` may be `in`
-void launch_aggm_stage(Vol in, Vol out, const u8 *armU, const u8 *armD, const u8 *armL, const u8 *armR, int D, int H, int W, int usd);
+// ca_cross / d_ca_cross of one volume in the caller's layout on the matrix-pipe kernels; `out` may be `in`.  Returns false, with
+// `out` untouched, when the volume holds an infinite, NaN or denormal element (one host read-back of a flag): the caller runs
+// the vector-ALU kernels instead.  aggm_stage_bytes: what it carves from the current Workspace scope.
+bool launch_aggm_stage(Vol in, Vol out, const u8 *armU, const u8 *armD, const u8 *armL, const u8 *armR, int D, int H, int W, int usd);
+size_t aggm_stage_bytes(int D, int H, int W, int usd);
 // both vertical passes with a strip's rows in registers (stm_kernels_aggv.hip); `tab` / `rec`: the table of stm_k_vwin_table
 bool aggv_supports(int usd);
 int aggv_table_top();
 int aggv_table_rec();
 void launch_pq_v12r(PQViews &v, int nviews, const uint32_t *tab, int rec, int H, int W, int G, int NC);
-void launch_to_pq(Vol in, float *pq, int D, int H, int W);         // stm_kernels_hslo.hip
+void launch_to_pq(Vol in, float *pq, int D, int H, int W, uint32_t *odd = nullptr); // stm_kernels_hslo.hip; odd: see stm_k_to_pq
 void launch_from_pq(const float *pq, Vol out, int D, int H, int W); // stm_kernels_aggm.hip
 // HSLO (stm_kernels_hslo.hip)
 void launch_hslo_wta(int nviews, const Vol *cost, const u8 *const *img_a, const u8 *const *img_b, const int *osign,

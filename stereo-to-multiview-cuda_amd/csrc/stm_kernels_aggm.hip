@@ -1245,18 +1245,39 @@ void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, co
 // The per-stage aggregation (ca_cross / d_ca_cross, d_ca_cross.cu:255-270) of ONE volume in the caller's layout on the
 // matrix-pipe kernels: volume -> PQ, H, V V, H, PQ -> `out` (which may be `in`: the device flavour returns the result in its
 // input volume, SURVEY A-Q11).  Two PQ volumes and the window table come from the current Workspace scope.
-void launch_aggm_stage(Vol in, Vol out, const u8 *armU, const u8 *armD, const u8 *armL, const u8 *armR, int D, int H, int W, int usd)
+static int vtab_rec(int usd)
+{
+    if (usd > 255) usd = 255;
+    const bool regs = aggv_supports(usd) && (agg_variant() / 10000000) % 10 != 1;
+    return regs ? aggv_table_rec() : 8 + 8 * ((2 * usd + 21) / 4 + 2);
+}
+size_t aggm_stage_bytes(int D, int H, int W, int usd)
+{
+    const int G = (W + 3) / 4, nT = (H + 15) / 16;
+    return 2 * pq_volume_floats(D, H, W) * sizeof(float) + (size_t)nT * G * vtab_rec(usd) * 4 + 4096;
+}
+bool launch_aggm_stage(Vol in, Vol out, const u8 *armU, const u8 *armD, const u8 *armL, const u8 *armR, int D, int H, int W, int usd)
 {
     const size_t VP = pq_volume_floats(D, H, W);
     float *m = Workspace::get<float>(2 * VP);
+    uint32_t *odd = Workspace::get<uint32_t>(64);
+    if (failed()) return true; // (error mode 1: nothing was launched, nothing to fall back to)
+    STM_CHECK(hipMemsetAsync(odd, 0, 4, stream()));
     PQViews v;
     for (int i = 0; i < 2; ++i) {
         v.pk[i] = nullptr; v.cen[i] = nullptr; v.a[i] = m; v.b[i] = m + VP;
         v.armU[i] = armU; v.armD[i] = armD; v.armL[i] = armL; v.armR[i] = armR; v.disp[i] = nullptr;
     }
-    launch_to_pq(in, m, D, H, W);
+    launch_to_pq(in, m, D, H, W, odd);
+    // An element that is not an ordinary number cannot go through masked multiply-adds (0 * inf = NaN would reach every pixel
+    // of the tile whose sweep passes it, where the reference only touches the windows that contain it, d_ca_cross_sum.cu:284-289)
+    uint32_t h_odd = 0;
+    STM_CHECK(hipMemcpyAsync(&h_odd, odd, 4, hipMemcpyDeviceToHost, stream()));
+    STM_CHECK(hipStreamSynchronize(stream()));
+    if (h_odd) return false;
     aggm_chain(v, 1, false, false, nullptr, D, 0, H, W, usd);
     launch_from_pq(m + VP, out, D, H, W);
+    return true;
 }
 
 } // namespace stm

@@ -89,7 +89,16 @@ __global__ __launch_bounds__(256) void stm_k_hslo_classes(HsloArgs a, float T, i
 
 // any layout -> PQ (only needed when the caller's volume is a plane table / slab / quads volume):
 // thread = (group g, quad qq of the chunk); grid (cdiv(4 G, 256), H, NC)
-template <bool QUAD> __global__ __launch_bounds__(256) void stm_k_to_pq(Vol in, f4 *__restrict__ out, int D, int H, int W, int G)
+// `odd` (may be null): set to 1 when the volume holds an element that is not an ordinary number -- infinite, NaN or denormal.  The
+// matrix-pipe aggregation adds window elements as acc += mask * b: a masked element must be finite for 0 * b to be 0, and
+// denormal operands are not guaranteed to survive the matrix instruction; the per-stage ca_cross then runs the vector-ALU
+// kernels, which touch an element only inside the windows that contain it (d_ca_cross_sum.cu:284-289).
+__device__ __forceinline__ bool pq_odd(float v)
+{
+    const uint32_t e = __builtin_bit_cast(uint32_t, v) & 0x7f800000u, m = __builtin_bit_cast(uint32_t, v) & 0x007fffffu;
+    return e == 0x7f800000u || (e == 0u && m != 0u);
+}
+template <bool QUAD> __global__ __launch_bounds__(256) void stm_k_to_pq(Vol in, f4 *__restrict__ out, int D, int H, int W, int G, uint32_t *__restrict__ odd)
 {
     const int t = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, c = blockIdx.z;
     const int g = t >> 2, q = 4 * c + (t & 3);
@@ -99,6 +108,12 @@ template <bool QUAD> __global__ __launch_bounds__(256) void stm_k_to_pq(Vol in, 
     for (int k = 0; k < 4; ++k) {
         const int x = 4 * g + k;
         px[k] = (x < W && 4 * q < D) ? load_quad<QUAD>(in, q, D, (size_t)y * W + x) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (odd) {
+        bool o = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o = o || pq_odd(px[k].x) || pq_odd(px[k].y) || pq_odd(px[k].z) || pq_odd(px[k].w);
+        if (o) *odd = 1u; // same value from every writer
     }
     f4 *o = out + (((size_t)c * H + y) * G + g) * 16 + 4 * (t & 3);
     o[0] = f4{px[0].x, px[1].x, px[2].x, px[3].x};
@@ -475,11 +490,11 @@ void hslo_passes(const HsloArgs &a, int nviews, int D, int zd, int H, int W, int
 
 } // namespace
 
-void launch_to_pq(Vol in, float *pq, int D, int H, int W)
+void launch_to_pq(Vol in, float *pq, int D, int H, int W, uint32_t *odd)
 {
     const int G = (W + 3) / 4, NC = (D + 15) / 16;
-    if (in.quad) STM_LAUNCH(stm_k_to_pq<true>, dim3(cdiv(4 * G, 256), H, NC), dim3(256), 0, stream(), in, (f4 *)pq, D, H, W, G);
-    else STM_LAUNCH(stm_k_to_pq<false>, dim3(cdiv(4 * G, 256), H, NC), dim3(256), 0, stream(), in, (f4 *)pq, D, H, W, G);
+    if (in.quad) STM_LAUNCH(stm_k_to_pq<true>, dim3(cdiv(4 * G, 256), H, NC), dim3(256), 0, stream(), in, (f4 *)pq, D, H, W, G, odd);
+    else STM_LAUNCH(stm_k_to_pq<false>, dim3(cdiv(4 * G, 256), H, NC), dim3(256), 0, stream(), in, (f4 *)pq, D, H, W, G, odd);
     STM_CHECK_LAUNCH();
 }
 
@@ -548,8 +563,8 @@ void launch_hslo_wta(int nviews, const Vol *cost, const u8 *const *img_a, const 
         cpq[v] = Workspace::get<float>(VP);
         apq[v] = Workspace::get<float>(VP);
         ProfScope p("hslo_to_pq");
-        if (cost[v].quad) STM_LAUNCH(stm_k_to_pq<true>, dim3(cdiv(4 * G, 256), H, NC), dim3(256), 0, stream(), cost[v], (f4 *)cpq[v], D, H, W, G);
-        else STM_LAUNCH(stm_k_to_pq<false>, dim3(cdiv(4 * G, 256), H, NC), dim3(256), 0, stream(), cost[v], (f4 *)cpq[v], D, H, W, G);
+        if (cost[v].quad) STM_LAUNCH(stm_k_to_pq<true>, dim3(cdiv(4 * G, 256), H, NC), dim3(256), 0, stream(), cost[v], (f4 *)cpq[v], D, H, W, G, (uint32_t *)nullptr);
+        else STM_LAUNCH(stm_k_to_pq<false>, dim3(cdiv(4 * G, 256), H, NC), dim3(256), 0, stream(), cost[v], (f4 *)cpq[v], D, H, W, G, (uint32_t *)nullptr);
         STM_CHECK_LAUNCH();
     }
     launch_hslo_wta_pq(nviews, cpq, apq, img_a, img_b, osign, disp, T, H1, H2, D, zd, H, W, elem_sz);

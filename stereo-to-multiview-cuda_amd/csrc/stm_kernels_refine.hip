@@ -121,6 +121,11 @@ struct IrvArgs {
     // vp[v][y][x], y in [0, H]: reliable (non-outlier) pixels, on the state BEFORE the first iteration, in the row segments of the
     // pixels (0 .. y - 1, x) -- a vertical prefix sum, so that the reliable pixels of a whole cross region are one subtraction
     const uint32_t *vp[2];
+    // device_diag(): bit 0 = an append past the list's capacity was dropped, bit 1 = the vote found a counter beyond the
+    // capacity, bit 2 = a list entry that is neither retired nor a pixel of the frame.  None can happen while the counters are
+    // cleared per call; the consumers clamp regardless (a replayed graph once ran with a stale counter, section 4 of DESIGN.md)
+    // and this word makes a clamp VISIBLE: stm_last_error() reports and clears it.
+    uint32_t *diag;
 };
 constexpr uint32_t IV_ACCEPTED = 0x80000000u; // list entry: pixel accepted in the previous iteration
 constexpr uint32_t IV_DEAD = 0xFFFFFFFFu;     // list entry: nothing left to do
@@ -326,6 +331,7 @@ __global__ __launch_bounds__(IC_T) void stm_k_irv_compact(IrvArgs a, uint32_t HW
     for (uint32_t j = 0; j < 4; ++j)
         if ((w >> (8 * j)) & 0xff) {
             if ((uint32_t)k < HW) list[k] = (p + j) | ((later >> j) & 1u ? IV_LATER : 0u); // the list holds HW entries: a counter that was not cleared can never write past it
+            else atomicOr(a.diag, 1u); // (never on the timed path)
             ++k;
         }
 }
@@ -402,14 +408,19 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
     const uint32_t nv_slot = (uint32_t)(nb + 1 + lane);                 // this lane's own no-vote slot
     const uint32_t sub_addr = (uint32_t)((wave * nslot * 4 + (lane & 3)) * 4); // LDS byte address of copy lane % 4 of slot 0
     const uint32_t lane2 = 2u * lane;
-    const int n = min(a.counts[v][0], H * W); // never past the list (capacity H W), whatever the counter holds
+    const int n_raw = a.counts[v][0];
+    const int n = min(n_raw, H * W); // never past the list (capacity H W), whatever the counter holds
+    if (n_raw > H * W && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.diag, 2u);
     const int stride = gridDim.x * IV_WAVES;
     int i = blockIdx.x * IV_WAVES + wave;
     uint32_t entry_next = i < n ? list[i] : IV_DEAD;
     for (; i < n; i += stride) {
         const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)entry_next);
         entry_next = i + stride < n ? list[i + stride] : IV_DEAD; // in flight while this outlier is processed
-        if ((entry & ~(IV_ACCEPTED | IV_LATER)) >= (uint32_t)(H * W)) continue; // IV_DEAD, or not a pixel of this frame (stale memory behind a wrong counter)
+        if ((entry & ~(IV_ACCEPTED | IV_LATER)) >= (uint32_t)(H * W)) { // IV_DEAD, or not a pixel of this frame (stale memory behind a wrong counter)
+            if (entry != IV_DEAD && lane == 0) atomicOr(a.diag, 4u);
+            continue;
+        }
         if ((entry & IV_LATER) && it == 0) continue; // S <= thresh_s in this iteration: rejected whatever the votes (the flag is ignored afterwards)
         if (entry & IV_ACCEPTED) { // accepted by the previous launch: bring this launch's write plane up to date
             if (lane == 0) {
@@ -587,6 +598,7 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
         }
     a.vp[0] = vp[0];
     a.vp[1] = nviews == 2 ? vp[1] : vp[0];
+    a.diag = device_diag();
     if (rounds == 0) return; // nothing observable happens (a host-flavour vote without an apply only fills scratch)
     if (HW >= IV_LATER) {
         fail("dr_irv: more than 2^30 - 1 pixels", "num_rows * num_cols", __FILE__, __LINE__);

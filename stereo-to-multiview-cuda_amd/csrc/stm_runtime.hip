@@ -42,6 +42,42 @@ void fail(const char *what, const char *expr, const char *file, int line)
 static thread_local hipStream_t g_stream = nullptr;
 hipStream_t stream() { return g_stream; }
 
+// ------------------------------------------------------------------ device-side diagnostics
+static std::mutex g_diag_mu;
+static uint32_t *g_diag[64] = {nullptr};
+uint32_t *device_diag()
+{
+    int dev = 0;
+    STM_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) {
+        fail("device index out of range", "hipGetDevice", __FILE__, __LINE__);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_diag_mu);
+    if (!g_diag[dev]) {
+        STM_CHECK(hipMalloc((void **)&g_diag[dev], 64));
+        STM_CHECK(hipMemset(g_diag[dev], 0, 64));
+    }
+    return g_diag[dev];
+}
+// reads and clears the current device's word (after the current stream has drained); 0 when it was never allocated
+static uint32_t take_device_diag()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    uint32_t *p;
+    {
+        std::lock_guard<std::mutex> lock(g_diag_mu);
+        p = g_diag[dev];
+    }
+    if (!p) return 0;
+    uint32_t v = 0;
+    if (hipStreamSynchronize(g_stream) != hipSuccess) return 0;
+    if (hipMemcpy(&v, p, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (v) (void)hipMemset(p, 0, 4);
+    return v;
+}
+
 // --------------------------------------------------------------- workspace
 // one slab per host thread and device (two threads may drive the same GPU on their own streams); grows
 // geometrically, never shrinks until the owning thread calls stm_release_workspace
@@ -51,7 +87,8 @@ struct WsState {
     size_t off = 0;
     std::vector<void *> retired; // old slabs still possibly referenced by in-flight kernels
 };
-static thread_local WsState g_ws[16];
+constexpr int WS_DEVS = 64; // one shared slab per device and thread (the same bound as the host-frame staging buffers)
+static thread_local WsState g_ws[WS_DEVS];
 
 static thread_local WsState *g_ws_bound = nullptr; // a private workspace bound by a frame stream (see below)
 
@@ -60,7 +97,11 @@ static WsState &ws()
     if (g_ws_bound) return *g_ws_bound;
     int dev = 0;
     STM_CHECK(hipGetDevice(&dev));
-    return g_ws[dev & 15];
+    if (dev < 0 || dev >= WS_DEVS) { // two devices must never share a slab: refuse instead of aliasing
+        fail("workspace: device index out of range", "hipGetDevice", __FILE__, __LINE__);
+        dev = 0; // only reached in error mode 1: the failed() flag keeps alloc() from handing anything out
+    }
+    return g_ws[dev];
 }
 
 // A private workspace for an object that replays captured work (stm_stream's hipGraph): its addresses must not move
@@ -252,7 +293,17 @@ int stm_version(void) { return 100; }
 void stm_set_stream(void *s) { stm::g_stream = (hipStream_t)s; }
 void *stm_get_stream(void) { return (void *)stm::g_stream; }
 void stm_set_error_mode(int m) { stm::g_error_mode = m; }
-const char *stm_last_error(void) { return stm::g_last_error.c_str(); }
+const char *stm_last_error(void)
+{
+    // a clamp inside a kernel (IrvArgs::diag) becomes an error of the calling thread here; this waits for the thread's stream
+    const uint32_t d = stm::take_device_diag();
+    if (d) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "dr_irv: the outlier list was inconsistent and was clamped (bits 0x%x: 1 = append past the capacity dropped, 2 = counter beyond the capacity, 4 = entry outside the frame); outliers may have been skipped", d);
+        stm::g_last_error = buf;
+    }
+    return stm::g_last_error.c_str();
+}
 void stm_release_workspace(void)
 {
     stm::ws_release();

@@ -75,6 +75,59 @@ def test_aggregation_on_uniform_random_volume(api, orc):
     assert np.array_equal(cross, ocross) and np.array_equal(acost, oacost)
 
 
+def _odd_volume(D, H, W, seed):
+    """uniform [0,2) costs with isolated elements that are not ordinary numbers (a common "invalid cost" marker), a huge value, a
+    denormal and negative values; each kind far enough from the others that every one of them meets windows of its own"""
+    rs = np.random.RandomState(seed)
+    cost = (rs.random_sample((D, H, W)) * 2).astype(np.float32)
+    marks = [np.float32(np.inf), np.float32(-np.inf), np.float32(np.nan), np.finfo(np.float32).max, np.float32(1e-40), np.float32(-3.5),
+             -np.finfo(np.float32).max, np.float32(-1e-42)]
+    spots = []
+    for k, v in enumerate(marks):
+        d, y, x = k % D, (7 + 11 * k) % H, (5 + 23 * k) % W
+        cost[d, y, x] = v
+        spots.append((d, y, x))
+    cost[D - 1, H // 2, 1:4] = np.float32(1e-39)  # a run of denormals: a window made of nothing else
+    return cost, spots
+
+
+def _same_with_nans(a, b):
+    """element equality where NaNs must sit at the same places (their payload bits are not compared)"""
+    na, nb = np.isnan(a), np.isnan(b)
+    return bool(np.array_equal(na, nb) and np.array_equal(a[~na], b[~nb]))
+
+
+@pytest.mark.parametrize("H,W,D,usd,lsd", [(72, 200, 12, 34, 17), (50, 90, 5, 9, 4), (40, 64, 20, 60, 30)])
+def test_ca_cross_nonfinite_and_denormal_planes(api, gpu_ready, orc, H, W, D, usd, lsd):
+    """The per-stage ca_cross / d_ca_cross on a caller's volume that holds +-inf, NaN, FLT_MAX, denormals and negative values.
+    A non-finite element may only reach the windows that contain it (d_ca_cross_sum.cu:284-289): the matrix-pipe kernels add
+    masked elements as acc += 0 * b, so such a volume must take the vector-ALU kernels (stm_k_to_pq raises the flag)."""
+    import torch
+    from stm_amd import device_api as dev
+    L, _ = rand_pair(H, W, 11 + H)
+    cost, spots = _odd_volume(D, H, W, 3 + W)
+    ocross, oacost = orc.ca_cross(L, cost, 6.0, 20.0, usd, lsd)
+    # the oracle itself: a NaN / infinity stays inside the windows that contain it -- most of the volume is finite
+    assert np.isfinite(oacost).mean() > 0.5 and not np.isfinite(oacost).all()
+    # host flavour
+    cross, acost = api.ca_cross(L, cost, 6.0, 20.0, usd, lsd)
+    assert np.array_equal(cross, ocross)
+    assert _same_with_nans(acost, oacost)
+    # device flavour: the result replaces the input planes (A-Q11)
+    dL = torch.from_numpy(L).cuda()
+    slab = torch.from_numpy(cost.copy()).cuda()
+    tab = torch.tensor([slab.data_ptr() + d * H * W * 4 for d in range(D)], dtype=torch.int64).cuda()
+    scratch = torch.zeros(D, H, W, dtype=torch.float32, device="cuda")
+    dcross = torch.zeros(4, H, W, dtype=torch.uint8, device="cuda")
+    dev.d_ca_cross(dL, tab, scratch, dcross, 6.0, 20.0, usd, lsd, D)
+    assert np.array_equal(dcross.cpu().numpy(), ocross)
+    assert _same_with_nans(slab.cpu().numpy(), oacost)
+    # and an ordinary volume right after it is back on the matrix-pipe kernels with the same answer as ever
+    plain = (np.random.RandomState(1).random_sample((D, H, W)) * 2).astype(np.float32)
+    _, a2 = api.ca_cross(L, plain, 6.0, 20.0, usd, lsd)
+    assert np.array_equal(a2, orc.ca_cross(L, plain, 6.0, 20.0, usd, lsd)[1])
+
+
 def test_wta_ties_and_order(api, orc):
     c = np.ones((9, 6, 10), np.float32)
     c[7, 1, 1] = 0.25
@@ -596,6 +649,37 @@ def test_frame_stream_graph_replay_survives_other_calls(gpu_ready, orc):
         dl, dr, out = host_api.adcensus_stm(f, W, H, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd,
                                             p.usd, p.lsd, p.thresh_s, p.thresh_h)
         assert np.array_equal(got[k][1], dl) and np.array_equal(got[k][2], dr) and np.array_equal(got[k][3], out), k
+    # no kernel had to clamp the region-voting list on the way (a clamp would be reported here, not swallowed)
+    import stm_amd
+    assert b"outlier list" not in stm_amd.lib().stm_last_error()
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_frame_stream_overlap_modes_in_a_child_process(gpu_ready, overlap):
+    """STM_STREAM_OVERLAP=0 (both buffer slots on one compute stream and workspace, as in round 2) and =1 (a stream and workspace
+    per slot) give the per-frame call's results.  The switch is read when the stream is created: a child process per mode."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import sys, os; sys.path.insert(0, %r)\n"
+        "import numpy as np, stm_amd\n"
+        "from stm_amd import device_api as dev, host_api, synth, video\n"
+        "H, W, D, zd = 48, 80, 8, 4\n"
+        "p = dev.FrameParams(num_disp=D, zero_disp=zd, usd=9, lsd=4)\n"
+        "frames = [synth.sbs_frame(H, W, D, zd, seed=synth.SEED + 300 + k)[0] for k in range(6)]\n"
+        "fs = video.FrameStream(H, W, p); got = []\n"
+        "for k, f in enumerate(frames):\n"
+        "    if k >= 2: got.append(fs.collect())\n"
+        "    fs.submit(f)\n"
+        "got.append(fs.collect()); got.append(fs.collect()); fs.close()\n"
+        "for k, f in enumerate(frames):\n"
+        "    dl, dr, out = host_api.adcensus_stm(f, W, H, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd, p.usd, p.lsd, p.thresh_s, p.thresh_h)\n"
+        "    assert got[k][0] == k and np.array_equal(got[k][1], dl) and np.array_equal(got[k][2], dr) and np.array_equal(got[k][3], out), k\n"
+        "print('ok')\n" % ROOT)
+    env = dict(os.environ, STM_STREAM_OVERLAP=overlap)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
 
 
 def test_video_cli_roundtrip(gpu_ready, orc, tmp_path):
