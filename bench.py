@@ -7,7 +7,8 @@ A step = one synthetic 1080p side-by-side frame per rank through the device-resi
 (stm_d_adcensus_stm: cost init -> cross aggregation -> WTA -> DCC / IRV x5 / bilateral -> 6 DIBR views ->
 interlacing).  Inputs are resident in HBM before the timed region.  Frames are independent, so ranks share no
 data-path collective (scaling = weak); the only communication is the RCCL broadcast of the input batch from
-rank 0 before timing starts.
+rank 0 before timing starts.  With N > 1 the pipelined scatter / gather loop of the C5 batch path
+(sharding.FrameBatchPipeline) is timed beside it and reported as `batch_movement` (never `value`).
 
 N > 1: one process per GPU.  Under `python -m torch.distributed.run` (RANK / WORLD_SIZE in the environment) this
 process is one of the ranks; started plainly (`python bench.py --gpus 8`) it launches torch.distributed.run itself as a
@@ -49,9 +50,9 @@ def parse():
     ap.add_argument("--stages", type=int, default=3, help="1 = cost+agg+WTA (config 2), 2 = +refinement (config 3), 3 = full frame; add 256 for HSLO before WTA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--agg-variant", type=int, default=0, help="0 = matrix-pipe aggregation (default), 10000 = vector-ALU kernels")
-    ap.add_argument("--batch", type=int, default=0, help="--gpus N > 1: frames per step (default N, one per rank); rank 0 scatters every "
-                    "step's frames and gathers its outputs INSIDE the timed region, double-buffered (sharding.FrameBatchPipeline)")
-    ap.add_argument("--no-batch-movement", action="store_true", help="--gpus N > 1: inputs resident on every rank before timing (the round-1/2 form)")
+    ap.add_argument("--batch", type=int, default=0, help="--gpus N > 1, the `batch_movement` leg: frames per step (default N, one per rank); rank 0 "
+                    "scatters every step's frames and gathers its outputs inside that leg's timed region, double-buffered (sharding.FrameBatchPipeline)")
+    ap.add_argument("--no-batch-movement", action="store_true", help="--gpus N > 1: skip the `batch_movement` leg (`value` is always the resident-input form)")
     ap.add_argument("--no-extras", action="store_true", help="skip the two-frames-in-flight and real-content legs and the window statistics behind roofline.issue (profiling passes)")
     return ap.parse_args()
 
@@ -167,49 +168,37 @@ def main():
     zd = D // 2
     p = dev.FrameParams(num_disp=D, zero_disp=zd)  # SURVEY 8d defaults: usd=34, lsd=17, 8 views, angle 18.43
     stm_amd.lib().stm_set_agg_variant(args.agg_variant)
-    moving = world > 1 and not args.no_batch_movement  # the C5 batch path: scatter / gather inside the timed region
-    B = (args.batch if args.batch > 0 else world) if moving else world
-    per_rank = len(sharding.shard_indices(B, rank, world))
+    # `value`: inputs resident on every rank before timing, one frame per rank and step.  The C5 batch path (scatter / gather per
+    # step) is a second, separately timed leg for N > 1 (`batch_movement`): its first hardware run is the driver's, so it must
+    # not be what the headline depends on.
+    movement_leg = world > 1 and not args.no_batch_movement
+    B = (args.batch if args.batch > 0 else world) if movement_leg else world
+    per_rank = 1
 
     # ---- input batch: generated on rank 0 -------------------------------------------------------------
-    move_dev = "cpu" if rehearsal else "cuda"  # where the scattered / gathered tensors live
-    batch = torch.zeros(B, H, 2 * W, 3, dtype=torch.uint8, device=move_dev if moving else "cuda") if (rank == 0 or not moving) else None
+    move_dev = "cpu" if rehearsal else "cuda"  # where the scattered / gathered tensors of the movement leg live
+    batch = torch.zeros(world, H, 2 * W, 3, dtype=torch.uint8, device="cuda")
     sbs_host = None
     if rank == 0:
-        frames = []
-        for r in range(B):
-            f, _ = synth.sbs_frame(H, W, D, zd, seed=synth.SEED + (r % max(world, 1)))
-            frames.append(f)
+        frames = [synth.sbs_frame(H, W, D, zd, seed=synth.SEED + r)[0] for r in range(world)]
         sbs_host = frames[0]
         batch.copy_(torch.from_numpy(np.stack(frames)))
-    if not moving:
-        # inputs resident in HBM on every rank before the timed region: RCCL broadcast of the batch (north_star), one frame per rank
+    # inputs resident in HBM on every rank before the timed region: RCCL broadcast of the batch (north_star), one frame per rank
+    if rehearsal:
+        hb = batch.cpu()
+        sharding.broadcast_batch(hb, src=0)
+        batch.copy_(hb)
+    else:
         sharding.broadcast_batch(batch, src=0)
-        mine = sharding.shard_indices(world, rank, world)
-        frame = batch[mine[0]].contiguous()
+    frame = batch[sharding.shard_indices(world, rank, world)[0]].contiguous()
 
     dl = torch.zeros(H, W, dtype=torch.float32, device="cuda")
     dr = torch.zeros_like(dl)
     out = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
-    pipe = None
-    if moving:
-        pipe = sharding.FrameBatchPipeline(B, (H, 2 * W, 3), torch.uint8,
-                                           {"disp_l": ((H, W), torch.float32), "disp_r": ((H, W), torch.float32), "interlaced": ((H, W, 3), torch.uint8)},
-                                           move_dev, rank, world)
-
-    def run_frame(fr, outs):
-        if rehearsal:  # host tensors in and out (gloo): compute on the GPU through the resident buffers
-            dev.d_adcensus_stm(fr.cuda(), dl, dr, out, p, stages=args.stages)
-            outs["disp_l"].copy_(dl); outs["disp_r"].copy_(dr); outs["interlaced"].copy_(out)
-            return
-        dev.d_adcensus_stm(fr, outs["disp_l"], outs["disp_r"], outs["interlaced"], p, stages=args.stages)
 
     def steps(n):
-        if moving:
-            pipe.run([batch] * n if rank == 0 else None, n, run_frame)
-        else:
-            for _ in range(n):
-                dev.d_adcensus_stm(frame, dl, dr, out, p, stages=args.stages)
+        for _ in range(n):
+            dev.d_adcensus_stm(frame, dl, dr, out, p, stages=args.stages)
 
     def barrier():
         torch.cuda.synchronize()
@@ -260,10 +249,13 @@ def main():
     n100 = max(100, args.steps)
     dt100 = timed(n100, False) if args.steps < 100 else dt
 
+    movement = batch_movement_leg(torch, dist, dev, sharding, synth, args, p, H, W, D, zd, B, rank, world, move_dev, rehearsal,
+                                  (dl, dr, out)) if movement_leg else None
+
     if rank == 0:
         V = float(D) * H * W * 4
         HW = float(H) * W
-        frames_per_step = B  # whole job
+        frames_per_step = world  # whole job: one frame per rank and step
         my_frames = float(per_rank * args.steps)  # frames behind this rank's kernel records
         L_host, R_host = np.ascontiguousarray(sbs_host[:, :W]), np.ascontiguousarray(sbs_host[:, W:])
         if args.no_extras:  # profiling passes: no launches besides the timed pipeline (the per-kernel averages stay clean)
@@ -286,10 +278,10 @@ def main():
         # 284-289): D x the sum of the window lengths over both views; pq_v12 does two vertical passes
         useful = {"pq_h": float(D) * sum_h, "pq_hw": float(D) * sum_h, "pq_v12": 2.0 * D * sum_v}
         traffic_all, traffic_src = {}, None
-        tj = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
         if os.path.exists(tj) and (H, W, D, args.agg_variant, args.stages) == (1080, 1920, 64, 0, 3):
             traffic_all = json.load(open(tj))
-            traffic_src = ("profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, FETCH x2 per "
+            traffic_src = ("profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, FETCH x2 per "
                            "MI355X_MICROARCH.md; taken on the commit named in its 'commit' key (profiles/README.md)")
         per_kernel = {}
         for k in AGG_KERNELS:
@@ -307,7 +299,7 @@ def main():
         dom = max(agg_names, key=lambda k: kern[k]["total_ms"])
         stage_ms = sum(kern[k]["total_ms"] for k in per_kernel) / my_frames
         stage_bytes = sum(alg[k] * kern[k]["launches"] for k in per_kernel) / my_frames
-        roofline = {"bound": per_kernel[dom]["bound"], "kernel": "stm_k_" + dom + ("t" if dom == "pq_v12" else ""),
+        roofline = {"bound": per_kernel[dom]["bound"], "kernel": {"pq_v12": "stm_k_pq_v12r" if p.usd <= 36 and args.agg_variant == 0 else "stm_k_pq_v12t", "pq_h": "stm_k_pq_hc", "pq_hw": "stm_k_pq_hs"}.get(dom, "stm_k_" + dom),
                     "achieved": per_kernel[dom]["achieved"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": per_kernel[dom]["traffic"],
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg[dom],
@@ -330,11 +322,9 @@ def main():
                               2: "config 2 + DCC + IRV x5 + bilateral (config 3)",
                               3: "full stereo->8-view frame: cost init + cross aggregation + WTA + DCC/IRV x5/bilateral + 6 DIBR views + interlacing"}[args.stages & 0xff]
                 + (" + scanline optimisation (HSLO) before WTA" if args.stages & 0x100 else ""),
-                "one frame per GPU per step" if not moving else "%d frames per step" % B),
+                "one frame per GPU per step"),
                        "stages": args.stages, "usd": p.usd, "lsd": p.lsd, "views": p.num_views,
-                       "sharding": ("frames, %d per step over %d ranks; rank 0 scatters each step's frames and gathers the outputs (disparities + interlaced "
-                                    "frame) inside the timed region, scatter of step k+1 and gather of step k-1 overlapped with the compute of step k "
-                                    "(sharding.FrameBatchPipeline, RCCL)" % (B, world)) if moving else "frames, 1 per rank, inputs resident before timing",
+                       "sharding": "frames, 1 per rank and step, inputs resident before timing (RCCL broadcast of the batch from rank 0)",
                        "aggregation": "matrix pipe (stm_kernels_aggm.hip)" if args.agg_variant == 0 else "agg_variant %d" % args.agg_variant},
             "rccl_world_size": rccl_world,
             "rate_over_100_frames": {"frames": n100 * frames_per_step, "frames_per_s": frames_per_step * n100 / dt100, "ms_per_frame": dt100 / (n100 * frames_per_step) * 1e3},
@@ -342,11 +332,16 @@ def main():
             "kernels_ms": {k: round(v, 4) for k, v in other.items()},
             "kernels_ms_source": "a separate %d-step run with HIP events around every named kernel (the timed region keeps events around the aggregation kernels only)" % nbreak,
         }
+        if movement is not None:
+            res["batch_movement"] = movement
         if world == 1 and not args.no_extras:
             res["rate_two_in_flight"] = two_in_flight(torch, dev, sbs_host, p, H, W, args.stages, max(30, min(args.steps, 100)))
             rc = real_content(torch, dev, synth, p, H, W, D, zd, args.stages, read_all)
             if rc:
                 res["real_content"] = rc
+            if (H, W, D, args.stages) == (1080, 1920, 64, 3):
+                res["rate_incl_pcie"] = rate_incl_pcie(sbs_host, p, H, W, D, zd, 40)
+                res["configs"] = config_sweep(torch, dev, synth)
         if rehearsal:
             res["invalid"] = "STM_BENCH_REHEARSAL=gloo: %d ranks on one GPU over gloo and host tensors -- a dry run of the multi-rank flow, not a measurement" % world
         bad = 0
@@ -370,6 +365,128 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def batch_movement_leg(torch, dist, dev, sharding, synth, args, p, H, W, D, zd, B, rank, world, move_dev, rehearsal, bufs):
+    """The C5 batch path as its own timed leg: per step a batch of B frames, rank 0 scatters every rank its frames and
+    gathers the packed outputs (one record per frame: two disparity maps + the interlaced frame), the scatter of step k+1 and the
+    gather of step k-1 in flight while step k computes.  Runs on every rank; returns the report on rank 0.  Never `value`."""
+    dl, dr, out = bufs
+    n = max(2, min(args.steps, 20))
+    batch = None
+    if rank == 0:
+        batch = torch.from_numpy(np.stack([synth.sbs_frame(H, W, D, zd, seed=synth.SEED + (r % world))[0] for r in range(B)])).to(move_dev)
+    pipe = sharding.FrameBatchPipeline(B, (H, 2 * W, 3), torch.uint8,
+                                       {"disp_l": ((H, W), torch.float32), "disp_r": ((H, W), torch.float32), "interlaced": ((H, W, 3), torch.uint8)},
+                                       move_dev, rank, world)
+
+    def run_frame(fr, outs):
+        if rehearsal:  # host tensors in and out (gloo): compute on the GPU through the resident buffers
+            dev.d_adcensus_stm(fr.cuda(), dl, dr, out, p, stages=args.stages)
+            outs["disp_l"].copy_(dl); outs["disp_r"].copy_(dr); outs["interlaced"].copy_(out)
+            return
+        dev.d_adcensus_stm(fr, outs["disp_l"], outs["disp_r"], outs["interlaced"], p, stages=args.stages)
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+    pipe.run([batch] * 2 if rank == 0 else None, 2, run_frame)  # warm-up
+    for k in pipe.stats:
+        pipe.stats[k] = 0 if k == "batches" else 0.0
+    sync()
+    t0 = time.perf_counter()
+    pipe.run([batch] * n if rank == 0 else None, n, run_frame)
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in pipe.stats.items()})
+    if rank != 0:
+        return None
+    dt = float(t.item())
+    return {"frames_per_step": B, "steps": n, "frames_per_s": B * n / dt, "ms_per_step": dt / n * 1e3,
+            "batch_bytes_in": pipe.bytes_in, "batch_bytes_out": pipe.bytes_out, "record_bytes_per_frame": pipe.rec_bytes,
+            "per_rank_ms": per_rank,
+            "how": "sharding.FrameBatchPipeline: one scatter + one gather (packed record) per step, every buffer allocated before the loop; "
+                   "per_rank_ms = host milliseconds per phase summed over the steps (stage = rank 0 copying frames into the per-rank scatter "
+                   "staging, wait_in / wait_out = blocked on the scatter / gather, compute_issue = launching the frames, assemble = rank 0 "
+                   "putting the gathered records into frame order)"}
+
+
+def rate_incl_pcie(sbs, p, H, W, D, zd, n):
+    """SURVEY 8d metric 1, second figure: the host-buffer boundary, PCIe included -- frames written into the stream's pinned
+    input buffer, results read in place (stm_stream_input_buffer / stm_stream_collect_view; what tools/host_rate.py (c) measures)."""
+    from stm_amd import video
+    fs = video.FrameStream(H, W, p)
+    try:
+        for _ in range(2):
+            fs.input_buffer()[...] = sbs
+            fs.submit_inplace()
+        fs.collect_view()
+        fs.collect_view()
+        t0 = time.perf_counter()
+        pending = 0
+        for _ in range(n):
+            if pending == 2:
+                fs.collect_view()
+                pending -= 1
+            fs.submit_inplace()
+            pending += 1
+        while pending:
+            fs.collect_view()
+            pending -= 1
+        dt = time.perf_counter() - t0
+    finally:
+        fs.close()
+    return {"frames": n, "frames_per_s": n / dt, "ms_per_frame": dt / n * 1e3, "bytes_in_per_frame": int(sbs.nbytes),
+            "bytes_out_per_frame": int(2 * H * W * 4 + H * W * 3),
+            "how": "stm_stream_* with two frames in flight: H2D of frame k+1 || compute of frame k || D2H of frame k-1, pinned buffers written / read in place"}
+
+
+def config_sweep(torch, dev, synth):
+    """The other BASELINE configurations on this build, 10 frames each (parity-test cases, not bench lines: each is compared with the
+    oracle at full size in tests/test_gpu_fullsize.py): frame rate, and for the aggregation kernel with the largest total time its
+    average launch time and HBM fraction (algorithmic bytes as for the headline)."""
+    out = {}
+    for name, H, W, D, stages in (("C2_cost_agg_wta", 1080, 1920, 64, 1), ("C3_hslo_refine", 1080, 1920, 64, 259),
+                                  ("C4_d128", 1080, 1920, 128, 3), ("C5_4k_d256", 2160, 3840, 256, 3)):
+        try:
+            zd = D // 2
+            p = dev.FrameParams(num_disp=D, zero_disp=zd)
+            sbs, _ = synth.sbs_frame(H, W, D, zd)
+            d_sbs = torch.from_numpy(sbs).cuda()
+            a = torch.zeros(H, W, dtype=torch.float32, device="cuda")
+            b = torch.zeros_like(a)
+            o = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
+            for _ in range(2):
+                dev.d_adcensus_stm(d_sbs, a, b, o, p, stages=stages)
+            torch.cuda.synchronize()
+            n = 10
+            dev.prof_reset()
+            dev.prof_enable(2)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                dev.d_adcensus_stm(d_sbs, a, b, o, p, stages=stages)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            dev.prof_enable(False)
+            V, HW = float(D) * H * W * 4, float(H) * W
+            alg = {"pq_h": 2 * (V + 18 * HW), "pq_v12": 2 * (2 * V + 2 * HW), "pq_hw": 2 * (V + 6 * HW)}
+            ks = {}
+            for k in alg:
+                cnt, ms = dev.prof_read(k)
+                if cnt:
+                    ks[k] = {"avg_launch_ms": ms / cnt, "launches_per_frame": cnt / float(n),
+                             "hbm_frac": alg[k] / (ms / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            dom = max(ks, key=lambda k: ks[k]["avg_launch_ms"] * ks[k]["launches_per_frame"]) if ks else None
+            out[name] = {"size": [H, W, D], "stages": stages, "frames": n, "frames_per_s": n / dt, "ms_per_frame": dt / n * 1e3,
+                         "dominant_kernel": dom, "kernels": ks}
+            del d_sbs, a, b, o
+        except Exception as e:  # a config that does not fit the box must not cost the headline its line
+            out[name] = {"error": repr(e)}
+    return out
 
 
 def two_in_flight(torch, dev, sbs_host, p, H, W, stages, n):

@@ -12,7 +12,9 @@ communication is moving the batch.  Two forms:
   the scatter of batch k+1 and the gather of batch k-1 are in flight while batch k computes.
 
 One process per GPU.  Status: exercised with world size 2 on gloo (tests/test_host_logic.py); never yet run on a
-multi-GPU node by the builder (one-GPU boxes only) -- the driver's N-GPU run is the first hardware run.
+multi-GPU node by the builder (one-GPU boxes only) -- the driver's N-GPU run is the first hardware run.  bench.py's
+headline for N > 1 is therefore the resident-input form (broadcast_batch before timing); the pipelined scatter / gather
+loop is timed beside it as an extra (`batch_movement`).
 """
 import torch
 import torch.distributed as dist
@@ -95,56 +97,132 @@ def process_batch(batch, run_frame, rank, world_size):
     return torch.stack(outs)
 
 
+def pack_layout(out_specs, align=16):
+    """Byte layout of one frame's outputs in ONE buffer, so that a batch needs a single gather: {name: (offset, nbytes, shape,
+    dtype)} and the total size.  Fields are aligned to `align` bytes (a float32 view needs a multiple of 4)."""
+    layout, off = {}, 0
+    for name, (shape, dtype) in out_specs.items():
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        layout[name] = (off, nbytes, tuple(shape), dtype)
+        off = (off + nbytes + align - 1) // align * align
+    return layout, off
+
+
 class FrameBatchPipeline:
     """Double-buffered scatter -> compute -> gather over a sequence of frame batches.
 
     in_shape: shape of one input frame (e.g. (H, 2W, 3), uint8); out_specs: {name: (shape, dtype)} of the per-frame
-    outputs.  run_frame(frame, outs) computes one frame into the dict of per-frame output tensors (views of the
-    pipeline's buffers, so nothing is copied).  batches: on rank `src` a sequence of [B][...] tensors on `device`
-    (ignored elsewhere).  on_result(k, {name: [B][...]}) is called on `dst` for every batch, in order."""
+    outputs.  run_frame(frame, outs) computes one frame into the dict of per-frame output tensors (views into the
+    pipeline's packed output buffer, so nothing is copied).  batches: on rank `src` a sequence of [B][...] tensors on `device`
+    (ignored elsewhere).  on_result(k, {name: [B][...]}) is called on `dst` for every batch, in order; the tensors are views of
+    a buffer that is reused two batches later.
+
+    Round 4: every buffer of the loop exists before the first step (scatter staging per rank on `src`, gather landing and
+    the assembled batch on `dst`: the timed loop allocates nothing), and the outputs of a frame are ONE packed byte record
+    (pack_layout), so a step issues one scatter and one gather instead of one gather per output.  `stats` (host milliseconds
+    per phase, summed over the batches of run()) tells a scaling run where its time went."""
 
     def __init__(self, frames_per_batch, in_shape, in_dtype, out_specs, device, rank, world_size, src=0, dst=0):
         self.B, self.rank, self.world, self.src, self.dst = frames_per_batch, rank, world_size, src, dst
         self.n_max = (frames_per_batch + world_size - 1) // world_size
         self.mine = shard_indices(frames_per_batch, rank, world_size)
+        self.layout, self.rec_bytes = pack_layout(out_specs)
         self.inbuf = [torch.zeros((self.n_max,) + tuple(in_shape), dtype=in_dtype, device=device) for _ in range(2)]
-        self.outbuf = [{k: torch.zeros((self.n_max,) + tuple(s), dtype=t, device=device) for k, (s, t) in out_specs.items()}
-                       for _ in range(2)]
+        self.outbuf = [torch.zeros((self.n_max, self.rec_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
+        multi = world_size > 1 and _active()
+        # rank src: one staging tensor per destination rank and buffer slot (a shard shorter than n_max keeps its zero tail)
+        self.stage = [[torch.zeros_like(self.inbuf[0]) for _ in range(world_size)] for _ in range(2)] if (multi and rank == src) else None
+        # rank dst: where the gather lands, and the batch in frame order
+        self.land = [[torch.empty_like(self.outbuf[0]) for _ in range(world_size)] for _ in range(2)] if (multi and rank == dst) else None
+        self.result = [torch.zeros((frames_per_batch, self.rec_bytes), dtype=torch.uint8, device=device) for _ in range(2)] if rank == dst else None
+        self.shards = [shard_indices(frames_per_batch, r, world_size) for r in range(world_size)]
+        self.bytes_in = frames_per_batch * self.inbuf[0][0].numel() * self.inbuf[0].element_size()
+        self.bytes_out = frames_per_batch * self.rec_bytes
+        self.stats = {"stage_ms": 0.0, "wait_in_ms": 0.0, "compute_issue_ms": 0.0, "wait_out_ms": 0.0, "assemble_ms": 0.0, "batches": 0}
+
+    def frame_views(self, buf_row):
+        """{name: tensor} views into one packed record (a row of the output buffer)."""
+        return {name: buf_row[off:off + nb].view(dtype).view(shape) for name, (off, nb, shape, dtype) in self.layout.items()}
+
+    def batch_views(self, packed):
+        """{name: [B][...]} views into an assembled batch of packed records."""
+        n = packed.shape[0]
+        return {name: packed[:, off:off + nb].view(dtype).view((n,) + shape) for name, (off, nb, shape, dtype) in self.layout.items()}
 
     def _scatter(self, k, batches):
-        b = batches[k] if self.rank == self.src else None
-        return scatter_frames(self.inbuf[k & 1], b, self.B, self.rank, self.world, self.src, async_op=True)
+        import time
+        slot = k & 1
+        if self.world == 1 or not _active():
+            idx = self.shards[0]
+            self.inbuf[slot][: len(idx)].copy_(batches[k][idx])
+            return None
+        scatter_list = None
+        if self.rank == self.src:
+            t0 = time.perf_counter()
+            b = batches[k]
+            for r in range(self.world):
+                idx = self.shards[r]
+                if idx:
+                    self.stage[slot][r][: len(idx)].copy_(b[idx])
+            scatter_list = self.stage[slot]
+            self.stats["stage_ms"] += (time.perf_counter() - t0) * 1e3
+        return dist.scatter(self.inbuf[slot], scatter_list, src=self.src, async_op=True)
+
+    def _gather(self, slot):
+        if self.world == 1 or not _active():
+            return None
+        return dist.gather(self.outbuf[slot], self.land[slot] if self.rank == self.dst else None, dst=self.dst, async_op=True)
 
     def run(self, batches, n_batches, run_frame, on_result=None):
+        import time
         if n_batches <= 0:
             return
+        st = self.stats
         pending_in = self._scatter(0, batches)
-        pending_out = [None, None]  # per buffer: list of (name, work, finish) of the gather still reading it
+        pending_out = [None, None]  # per buffer slot: (batch index, work) of the gather still reading it
 
-        def drain(slot, k):
+        def drain(slot):
             if pending_out[slot] is None:
                 return
-            res = {}
-            for name, work, finish in pending_out[slot]:
-                if work is not None:
-                    work.wait()
-                res[name] = finish()
+            k, work = pending_out[slot]
             pending_out[slot] = None
-            if on_result is not None and self.rank == self.dst:
-                on_result(k, res)
+            t0 = time.perf_counter()
+            if work is not None:
+                work.wait()
+            t1 = time.perf_counter()
+            st["wait_out_ms"] += (t1 - t0) * 1e3
+            if self.rank != self.dst:
+                return
+            res = self.result[slot]
+            if self.land is None:  # a single process: the local buffer is the batch
+                res[: len(self.shards[0])].copy_(self.outbuf[slot][: len(self.shards[0])])
+            else:
+                for r in range(self.world):
+                    idx = self.shards[r]
+                    if idx:
+                        res[idx] = self.land[slot][r][: len(idx)]
+            st["assemble_ms"] += (time.perf_counter() - t1) * 1e3
+            if on_result is not None:
+                on_result(k, self.batch_views(res))
 
         for k in range(n_batches):
+            slot = k & 1
+            t0 = time.perf_counter()
             if pending_in is not None:
                 pending_in.wait()  # this batch's frames have arrived
+            st["wait_in_ms"] += (time.perf_counter() - t0) * 1e3
             pending_in = self._scatter(k + 1, batches) if k + 1 < n_batches else None  # in flight while batch k computes
-            drain(k & 1, k - 2)  # the gather of batch k-2 must be done with this output buffer
-            ins, outs = self.inbuf[k & 1], self.outbuf[k & 1]
+            drain(slot)  # the gather of batch k-2 must be done with this output buffer
+            t0 = time.perf_counter()
+            ins, outs = self.inbuf[slot], self.outbuf[slot]
             for i in range(len(self.mine)):
-                run_frame(ins[i], {name: t[i] for name, t in outs.items()})
-            pending_out[k & 1] = []
-            for name, t in outs.items():
-                work, finish = gather_frames(t, self.B, self.rank, self.world, self.dst, async_op=True)
-                pending_out[k & 1].append((name, work, finish))
+                run_frame(ins[i], self.frame_views(outs[i]))
+            st["compute_issue_ms"] += (time.perf_counter() - t0) * 1e3
+            pending_out[slot] = (k, self._gather(slot))
+            st["batches"] += 1
         for k in (n_batches - 2, n_batches - 1):
             if k >= 0:
-                drain(k & 1, k)
+                drain(k & 1)

@@ -98,13 +98,31 @@ def _pipeline_worker(rank, world, port, q):
     pipe = sharding.FrameBatchPipeline(B, (4, 6, 3), torch.uint8, {"rowsum": ((4,), torch.float32), "neg": ((4, 6, 3), torch.uint8)},
                                        "cpu", rank, world)
     got = []
+    calls = {"gather": 0, "scatter": 0}
+    real_gather, real_scatter = dist.gather, dist.scatter
+
+    def counting_gather(*a, **kw):
+        calls["gather"] += 1
+        return real_gather(*a, **kw)
+
+    def counting_scatter(*a, **kw):
+        calls["scatter"] += 1
+        return real_scatter(*a, **kw)
+    dist.gather, dist.scatter = counting_gather, counting_scatter
+    stage_ids = [id(t) for slot in (pipe.stage or []) for t in slot]
 
     def run_frame(frame, outs):
         outs["rowsum"].copy_(frame.to(torch.float32).sum(dim=(1, 2)))
         outs["neg"].copy_(255 - frame)
 
     pipe.run(batches, NB, run_frame, on_result=lambda k, res: got.append((k, {n: t.clone() for n, t in res.items()})))
+    dist.gather, dist.scatter = real_gather, real_scatter
+    # one scatter and ONE gather per batch (the outputs of a frame travel as one packed record), every buffer made before the loop
+    assert calls == {"gather": NB, "scatter": NB}, calls
+    assert pipe.stats["batches"] == NB and stage_ids == [id(t) for slot in (pipe.stage or []) for t in slot]
+    assert pipe.rec_bytes == 16 + 80 and pipe.bytes_out == B * pipe.rec_bytes and pipe.bytes_in == B * 4 * 6 * 3
     if rank == 0:
+        assert pipe.stage is not None and len(pipe.stage[0]) == world and pipe.land is not None
         ok = [k for k, _ in got] == list(range(NB))
         for k, res in got:
             ok = ok and torch.equal(res["rowsum"], batches[k].to(torch.float32).sum(dim=(2, 3))) and torch.equal(res["neg"], 255 - batches[k])
