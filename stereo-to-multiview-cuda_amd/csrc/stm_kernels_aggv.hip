@@ -248,8 +248,8 @@ VR_end_%=_\@:
         v_mov_b32 v[221+4*((\i)&1)], v[208+\i]
         v_mov_b32 v[222+4*((\i)&1)], v[212+\i]
         v_mov_b32 v[223+4*((\i)&1)], v[216+\i]
-        v_add_u32 v[244+((\i)&1)], s92, %[vst]
-        s_add_u32 s92, s92, %[rsb]
+        v_add_u32 v[244+((\i)&1)], s85, %[vst]
+        s_add_u32 s85, s85, %[rsb]
         s_nop 0
         .if (VR_EXP & 2) == 0
         buffer_store_dwordx4 v[220+4*((\i)&1):223+4*((\i)&1)], v[244+((\i)&1)], s[20:23], 0 offen nt
@@ -271,52 +271,14 @@ VR_end_%=_\@:
         s_add_u32 s27, %[nT], 3               ; the second pass runs three tiles behind
         s_mov_b64 s[86:87], 0
         s_mov_b64 s[88:89], 0
-        .macro VR_STEP lb
-        ; ------------------------------------------------------------ this step's tiles: u (first pass), u - 3 (second pass)
-        s_waitcnt lgkmcnt(0)                  ; their headers, requested a step ago
-        s_mov_b32 s81, s86
-        s_cmp_ge_i32 s24, 0
-        s_cselect_b32 s82, s87, 0
-        s_cmp_lt_i32 s24, %[nT]
-        s_cselect_b32 s82, s82, 0             ; first-pass tiles past the image: no window rows (their rows are zeros)
-        .if VR_EXP & 1
+        s_mov_b32 s81, 0                      ; the first step has no tiles
         s_mov_b32 s82, 0
-        .endif
-        s_sub_i32 s28, s24, 3
-        s_mov_b32 s83, s88
-        s_cmp_ge_i32 s28, 0
-        s_cselect_b32 s84, s89, 0
-        .if VR_EXP & 1
+        s_mov_b32 s83, 0
         s_mov_b32 s84, 0
-        .endif
-        ; headers of the next step's tiles (tile indices clamped into the table; unused entries are masked above)
-        s_sub_u32 s93, %[nT], 1
-        s_add_i32 s92, s24, 1
-        s_max_i32 s92, s92, 0
-        s_min_i32 s92, s92, s93
-        s_mul_i32 s92, s92, %[tstep]
-        s_load_dwordx2 s[86:87], %[trow], s92
-        s_sub_i32 s92, s24, 2
-        s_max_i32 s92, s92, 0
-        s_min_i32 s92, s92, s93
-        s_mul_i32 s92, s92, %[tstep]
-        s_load_dwordx2 s[88:89], %[trow], s92
-        ; ------------------------------------------------------------ first masks of the first pass
-        s_cmp_eq_u32 s82, 0
-        s_cbranch_scc1 VR_noissue1_%=_\@
-        s_mov_b32 s94, s81
-        s_mov_b32 s95, s82
-        s_add_u32 s96, s25, 16                ; row 16 u - 36 = row 16 u + 36 - 72, and -72 = 16 (mod 88)
-        s_sub_u32 s31, s96, 88
-        s_cmp_ge_u32 s96, 88
-        s_cselect_b32 s96, s31, s96
-        s_movk_i32 s29, 88
-        s_mul_i32 s92, s24, %[tstep]
-        s_add_u32 s92, s92, 32
-        s_add_u32 s98, %[trow_lo], s92
-        s_addc_u32 s99, %[trow_hi], 0
-        VR_SWEEP_ISSUE
-VR_noissue1_%=_\@:
+        s_sub_i32 s28, s24, 3
+        .macro VR_STEP lb
+        ; s81..s84 = (q0, n) of this step's first-pass tile u and second-pass tile u - 3, s28 = u - 3: set at the end of the step
+        ; before, where the first masks of this step's first pass were requested too
         ; ------------------------------------------------------------ the rows loaded during the last step -> ring 1
         s_cmp_lt_i32 s24, -3
         s_cbranch_scc1 VR_nocopy_%=_\@
@@ -334,56 +296,8 @@ VR_noissue1_%=_\@:
         s_set_gpr_idx_off
         .endif
 VR_nocopy_%=_\@:
-        ; ------------------------------------------------------------ rows [16 u + 68, 16 u + 84) -> the landing registers just emptied
-        ; (rows above or below the image read zeros from an empty buffer; the row offset is scalar, and whether or not the
-        ; range check sees it, a row of the image passes)
-        s_lshl_b32 s90, s24, 4
-        s_add_i32 s90, s90, 68
-        s_add_i32 s91, s90, 15
-        s_cmp_lt_u32 s91, %[H]                ; (unsigned: also false for rows above the image)
-        s_cbranch_scc0 VR_slowloads_%=_\@
-        s_cmp_lt_u32 s90, %[H]
-        s_cbranch_scc0 VR_slowloads_%=_\@
-        ; all sixteen rows inside the image (every step but the first and the last few): one scalar add per row
-        s_mov_b32 s18, %[range]
-        s_mul_i32 s91, s90, %[rsb]
-        VR_LOAD_FAST \lb, 0
-        VR_LOAD_FAST \lb, 1
-        VR_LOAD_FAST \lb, 2
-        VR_LOAD_FAST \lb, 3
-        VR_LOAD_FAST \lb, 4
-        VR_LOAD_FAST \lb, 5
-        VR_LOAD_FAST \lb, 6
-        VR_LOAD_FAST \lb, 7
-        VR_LOAD_FAST \lb, 8
-        VR_LOAD_FAST \lb, 9
-        VR_LOAD_FAST \lb, 10
-        VR_LOAD_FAST \lb, 11
-        VR_LOAD_FAST \lb, 12
-        VR_LOAD_FAST \lb, 13
-        VR_LOAD_FAST \lb, 14
-        VR_LOAD_FAST \lb, 15
-        s_branch VR_loaded_%=_\@
-VR_slowloads_%=_\@:
-        VR_LOAD_ROW \lb, 0
-        VR_LOAD_ROW \lb, 1
-        VR_LOAD_ROW \lb, 2
-        VR_LOAD_ROW \lb, 3
-        VR_LOAD_ROW \lb, 4
-        VR_LOAD_ROW \lb, 5
-        VR_LOAD_ROW \lb, 6
-        VR_LOAD_ROW \lb, 7
-        VR_LOAD_ROW \lb, 8
-        VR_LOAD_ROW \lb, 9
-        VR_LOAD_ROW \lb, 10
-        VR_LOAD_ROW \lb, 11
-        VR_LOAD_ROW \lb, 12
-        VR_LOAD_ROW \lb, 13
-        VR_LOAD_ROW \lb, 14
-        VR_LOAD_ROW \lb, 15
-VR_loaded_%=_\@:
         s_cmp_lt_i32 s24, 0
-        s_cbranch_scc1 VR_stores_%=_\@
+        s_cbranch_scc1 VR_loads_%=_\@
         ; ------------------------------------------------------------ first pass of tile u
         s_cmp_eq_u32 s82, 0
         s_cbranch_scc1 VR_zero1_%=_\@
@@ -439,25 +353,73 @@ VR_noissue2_%=_\@:
         VR_PUT4 104, 216
         s_set_gpr_idx_off
         .endif
+VR_loads_%=_\@:
+        ; ------------------------------------------------------------ rows [16 u + 68, 16 u + 84) -> the landing registers just emptied
+        ; (rows above or below the image read zeros from an empty buffer; the row offset is scalar, and whether or not the
+        ; range check sees it, a row of the image passes)
+        s_lshl_b32 s90, s24, 4
+        s_add_i32 s90, s90, 68
+        s_add_i32 s91, s90, 15
+        s_cmp_lt_u32 s91, %[H]                ; (unsigned: also false for rows above the image)
+        s_cbranch_scc0 VR_slowloads_%=_\@
+        s_cmp_lt_u32 s90, %[H]
+        s_cbranch_scc0 VR_slowloads_%=_\@
+        ; all sixteen rows inside the image (every step but the first and the last few): one scalar add per row
+        s_mov_b32 s18, %[range]
+        s_mul_i32 s91, s90, %[rsb]
+        VR_LOAD_FAST \lb, 0
+        VR_LOAD_FAST \lb, 1
+        VR_LOAD_FAST \lb, 2
+        VR_LOAD_FAST \lb, 3
+        VR_LOAD_FAST \lb, 4
+        VR_LOAD_FAST \lb, 5
+        VR_LOAD_FAST \lb, 6
+        VR_LOAD_FAST \lb, 7
+        VR_LOAD_FAST \lb, 8
+        VR_LOAD_FAST \lb, 9
+        VR_LOAD_FAST \lb, 10
+        VR_LOAD_FAST \lb, 11
+        VR_LOAD_FAST \lb, 12
+        VR_LOAD_FAST \lb, 13
+        VR_LOAD_FAST \lb, 14
+        VR_LOAD_FAST \lb, 15
+        s_branch VR_loaded_%=_\@
+VR_slowloads_%=_\@:
+        VR_LOAD_ROW \lb, 0
+        VR_LOAD_ROW \lb, 1
+        VR_LOAD_ROW \lb, 2
+        VR_LOAD_ROW \lb, 3
+        VR_LOAD_ROW \lb, 4
+        VR_LOAD_ROW \lb, 5
+        VR_LOAD_ROW \lb, 6
+        VR_LOAD_ROW \lb, 7
+        VR_LOAD_ROW \lb, 8
+        VR_LOAD_ROW \lb, 9
+        VR_LOAD_ROW \lb, 10
+        VR_LOAD_ROW \lb, 11
+        VR_LOAD_ROW \lb, 12
+        VR_LOAD_ROW \lb, 13
+        VR_LOAD_ROW \lb, 14
+        VR_LOAD_ROW \lb, 15
+VR_loaded_%=_\@:
+        s_cmp_lt_i32 s24, 0
+        s_cbranch_scc1 VR_end_of_step_%=_\@
         ; ------------------------------------------------------------ second pass of tile u - 3
         s_cmp_eq_u32 s84, 0
         s_cbranch_scc1 VR_zero2_%=_\@
         VR_SWEEP_RUN 104
-        s_branch VR_stores_%=_\@
+        s_branch VR_end_of_step_%=_\@
 VR_zero2_%=_\@:
         VR_ZERO_ACC
-VR_stores_%=_\@:
+VR_end_of_step_%=_\@:
         ; registers 4b..4b+3 of lane 16q + n = out[rows 16 v + 4q .. + 3][column b][hypothesis n]: one float4 (four columns) per
         ; row.  Always four stores (a step's loads are counted against them); before tile 0 into an empty buffer
         s_cmp_ge_i32 s28, 0
         s_cselect_b32 s22, %[range], 0
-        s_lshl_b32 s92, s28, 4
-        s_mul_i32 s92, s92, %[rsb]
-        VR_STORE_ROWS 0
-        VR_STORE_ROWS 1
-        VR_STORE_ROWS 2
-        VR_STORE_ROWS 3
-        ; ------------------------------------------------------------ next step
+        s_lshl_b32 s85, s28, 4
+        s_mul_i32 s85, s85, %[rsb]
+        ; ------------------------------------------------------------ the next step: ring indices, tiles, first masks -- in front of
+        ; the stores, so that the masks travel behind them and behind the next step's row moves
         s_add_u32 s25, s25, 16
         s_sub_u32 s31, s25, 88
         s_cmp_ge_u32 s25, 88
@@ -467,6 +429,51 @@ VR_stores_%=_\@:
         s_cmp_ge_u32 s26, 100
         s_cselect_b32 s26, s31, s26
         s_add_i32 s24, s24, 1
+        s_waitcnt lgkmcnt(0)                  ; the headers of its tiles, requested a step ago
+        s_mov_b32 s81, s86
+        s_cmp_ge_i32 s24, 0
+        s_cselect_b32 s82, s87, 0
+        s_cmp_lt_i32 s24, %[nT]
+        s_cselect_b32 s82, s82, 0             ; first-pass tiles past the image: no window rows (their rows are zeros)
+        s_sub_i32 s28, s24, 3
+        s_mov_b32 s83, s88
+        s_cmp_ge_i32 s28, 0
+        s_cselect_b32 s84, s89, 0
+        .if VR_EXP & 1
+        s_mov_b32 s82, 0
+        s_mov_b32 s84, 0
+        .endif
+        ; headers of the tiles of the step after it (tile indices clamped into the table; unused entries are masked above)
+        s_sub_u32 s93, %[nT], 1
+        s_add_i32 s92, s24, 1
+        s_max_i32 s92, s92, 0
+        s_min_i32 s92, s92, s93
+        s_mul_i32 s92, s92, %[tstep]
+        s_load_dwordx2 s[86:87], %[trow], s92
+        s_sub_i32 s92, s24, 2
+        s_max_i32 s92, s92, 0
+        s_min_i32 s92, s92, s93
+        s_mul_i32 s92, s92, %[tstep]
+        s_load_dwordx2 s[88:89], %[trow], s92
+        s_cmp_eq_u32 s82, 0
+        s_cbranch_scc1 VR_noissue1_%=_\@
+        s_mov_b32 s94, s81
+        s_mov_b32 s95, s82
+        s_add_u32 s96, s25, 16                ; row 16 u - 36 = row 16 u + 36 - 72, and -72 = 16 (mod 88)
+        s_sub_u32 s31, s96, 88
+        s_cmp_ge_u32 s96, 88
+        s_cselect_b32 s96, s31, s96
+        s_movk_i32 s29, 88
+        s_mul_i32 s92, s24, %[tstep]
+        s_add_u32 s92, s92, 32
+        s_add_u32 s98, %[trow_lo], s92
+        s_addc_u32 s99, %[trow_hi], 0
+        VR_SWEEP_ISSUE
+VR_noissue1_%=_\@:
+        VR_STORE_ROWS 0
+        VR_STORE_ROWS 1
+        VR_STORE_ROWS 2
+        VR_STORE_ROWS 3
         .endm
 VR_loop_%=:
         VR_STEP 88
