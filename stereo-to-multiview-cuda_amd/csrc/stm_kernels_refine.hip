@@ -751,101 +751,6 @@ __global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_bilateral_r(const float *_
                 irow[4 * j] = u.x; irow[4 * j + 1] = u.y; irow[4 * j + 2] = u.z; irow[4 * j + 3] = u.w;
             }
         }
-        const float *krow = spatial + y * KW; // uniform address -> scalar loads
-#pragma unroll
-        for (int x = 0; x < KW; ++x) {
-            const float w = krow[x];
-            const f2 w2 = {w, w};
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f2 v = {row[x + 2 * h], row[x + 2 * h + 1]};
-                const f2 t = v * w2;
-                acc[h] = acc[h] + t;
-            }
-        }
-    }
-    const float res[4] = {acc[0].x, acc[0].y, acc[1].x, acc[1].y};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (gx + i < W) {
-            const float va = tile[(threadIdx.y + R) * TW + threadIdx.x * 4 + i + R];
-            const float q = res[i] / norm;
-            out[(size_t)gy * W + gx + i] = (va < q) ? q : va; // d_filter_gaussian.cu:84-87
-        }
-    }
-}
-
-// INTMAP (the frame pipeline's call): the maps hold integer-valued disparities whose differences stay inside the colour LUT --
-// WTA writes d - zd, region voting bin - zd, so any two values differ by at most D - 1 = ncolor - 1.  The kernel is bound by
-// vector-instruction issue (95 M wave instructions, every one 4 cycles: profiles/r03_pmc_sq_aggm.txt), 13 per pixel pair and tap,
-// of which 8 only produce the LUT address (subtract, |.| -> int, clamp, shift, twice).  With a second tile holding 4 x (value +
-// bias) as integers the LUT's BYTE OFFSET is one v_sad_u32 per pixel (|4a - 4b| = 4 |a - b|, exact), no clamp needed; weights
-// and both running sums are computed exactly as before from the float tile.  The per-stage filter_bilateral_1 (arbitrary
-// floats) keeps the general form.
-template <int R, bool INTMAP>
-__global__ __launch_bounds__(SF_TX *SF_TY) void stm_k_bilateral_r(const float *__restrict__ in0, float *__restrict__ out0,
-                                                                 const float *__restrict__ in1, float *__restrict__ out1,
-                                                                 const float *__restrict__ spatial,
-                                                                 const float *__restrict__ color, int H, int W, int ncolor)
-{
-    const float *__restrict__ in = blockIdx.z ? in1 : in0; // both views of a frame share the launch
-    float *__restrict__ out = blockIdx.z ? out1 : out0;
-    constexpr int KW = 2 * R + 1, NF = (KW + 3 + 3) / 4 * 4;
-    constexpr int TW = (SF_TX * 4 + 2 * R + 3) / 4 * 4 + 4, TH = SF_TY + 2 * R;
-    __shared__ float4 tile4[TH * TW / 4];
-    __shared__ uint4 itile4[INTMAP ? TH * TW / 4 : 1];
-    extern __shared__ float ck[]; // colour LUT, ncolor entries
-    float *tile = (float *)tile4;
-    uint32_t *itile = (uint32_t *)itile4;
-    const int tid = threadIdx.y * SF_TX + threadIdx.x;
-    const int x0 = blockIdx.x * SF_TX * 4, y0 = blockIdx.y * SF_TY;
-    for (int i = tid; i < TH * TW; i += SF_TX * SF_TY) {
-        const int ty = i / TW, tx = i - ty * TW;
-        const int gx = min(max(x0 + tx - R, 0), W - 1), gy = min(max(y0 + ty - R, 0), H - 1);
-        const float t = in[(size_t)gy * W + gx];
-        tile[i] = t;
-        if (INTMAP) itile[i] = (uint32_t)(((int)t + (1 << 20)) * 4);
-    }
-    for (int i = tid; i < ncolor; i += SF_TX * SF_TY) ck[i] = color[i];
-    __syncthreads();
-    const int gx = x0 + threadIdx.x * 4, gy = y0 + threadIdx.y;
-    if (gx >= W || gy >= H) return;
-    // The four pixels are kept as two float2 pairs: weight, norm and result updates are v_pk_mul_f32 / v_pk_add_f32
-    // (two pixels per instruction, each component rounded exactly like the scalar operation it replaces).
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const uint32_t ck_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)ck; // the LUT's address inside LDS
-    float va[4];
-    uint32_t ia[4];
-    f2 res[2] = {{0.f, 0.f}, {0.f, 0.f}}, norm[2] = {{0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        va[i] = tile[(threadIdx.y + R) * TW + threadIdx.x * 4 + i + R];
-        ia[i] = INTMAP ? itile[(threadIdx.y + R) * TW + threadIdx.x * 4 + i + R] : 0u;
-    }
-    for (int y = 0; y < KW; ++y) {
-        float row[NF];
-        uint32_t irow[NF];
-        const float4 *src = (const float4 *)(tile + (threadIdx.y + y) * TW + threadIdx.x * 4);
-        const uint4 *isrc = (const uint4 *)(itile + (threadIdx.y + y) * TW + threadIdx.x * 4);
-#pragma unroll
-        for (int j = 0; j < NF / 4; ++j) {
-            const float4 t = src[j];
-            row[4 * j] = t.x; row[4 * j + 1] = t.y; row[4 * j + 2] = t.z; row[4 * j + 3] = t.w;
-            if (INTMAP) {
-                const uint4 u = isrc[j];
-                irow[4 * j] = u.x; irow[4 * j + 1] = u.y; irow[4 * j + 2] = u.z; irow[4 * j + 3] = u.w;
-            }
-        }
-        // the same row once more, shifted by one element: a pixel pair at an ODD tap offset is then an aligned register pair too
-        // (the packed multiplies want their two floats in an even / odd register pair; without this copy every odd tap cost
-        // two v_mov).  Read from LDS as dword pairs: no vector-ALU instruction
-        f2 rowS[NF / 2];
-        {
-            const float *srcs = tile + (threadIdx.y + y) * TW + threadIdx.x * 4 + 1;
-#pragma unroll
-            for (int j = 0; j < NF / 2 - 1; ++j) rowS[j] = f2{srcs[2 * j], srcs[2 * j + 1]};
-            rowS[NF / 2 - 1] = f2{srcs[NF - 2], 0.f}; // (the last element would lie past the tile row; no tap reads it)
-        }
         const float *krow = spatial + y * KW;
 #pragma unroll
         for (int x = 0; x < KW; ++x) {
