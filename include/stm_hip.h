@@ -54,6 +54,9 @@ void        stm_set_stream(void *hip_stream);
 void       *stm_get_stream(void);
 /* 0 = print + exit(1) like cuda_utils.h:12-21 (default); 1 = record, return, keep going */
 void        stm_set_error_mode(int mode);
+/* the calling thread's last error text.  It also waits for the thread's stream and reads (and clears) a device-side word that
+ * the region-voting kernels set if they had to clamp their outlier list -- a condition that cannot arise while the library
+ * clears its counters per call, reported instead of swallowed if it ever does. */
 const char *stm_last_error(void);
 /* frees the cached device workspace (the reference cudaMalloc/cudaFree's per call) */
 void        stm_release_workspace(void);
@@ -70,7 +73,8 @@ int         stm_prof_read(const char *kernel, float *total_ms);
  * (stm_kernels_agg.hip; the low digits then select their tunables), 1000000 = separate initial-cost kernel instead of
  * computing the costs inside the first pass, 1000 / 2000 = the cost-computing pass as one block per segment (128- / 192-pixel
  * segments) instead of the row walk, 10 = the volume-reading horizontal passes as one block per segment instead of the row walk
- * (20: only for num_disp > 64), 200 = view synthesis and interlacing as two kernels.  Every accepted variant produces identical
+ * (20: only for num_disp > 64), 200 = view synthesis and interlacing as two kernels, 10000000 = the vertical passes on the LDS-ring
+ * kernel of round 3 instead of the register-ring kernel (stm_kernels_aggv.hip).  Every accepted variant produces identical
  * results (tests/test_gpu_parity.py::test_device_frame_agg_variants).  The
  * digit N00000 (timing experiments that skip parts of kernels) is ignored here: it exists only in libstm_hip_timing.so,
  * a separate build of the same sources with -DSTM_TIMING (csrc/Makefile, `make timing`). */
