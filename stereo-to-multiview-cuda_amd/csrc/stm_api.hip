@@ -688,11 +688,15 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
 
     al = carve_arms(HW);
     ar = carve_arms(HW);
+    uint32_t *htab = nullptr;
     {
         const uint32_t *pk[2] = {pk_l, pk_r};
         u8 *u[2] = {al.up, ar.up}, *d[2] = {al.down, ar.down}, *l[2] = {al.left, ar.left}, *r[2] = {al.right, ar.right};
         const uint32_t *wide[2] = {pre ? pre[2] : nullptr, pre ? pre[3] : nullptr};
-        launch_cross_arms2(2, pk, u, d, l, r, ucd, lcd, usd, lsd, H, W, pre ? wide : nullptr);
+        // the last aggregation pass's horizontal window table comes out of the same kernel (it has the arms in registers)
+        const size_t hw_dw = matrix_pipe ? aggm_frame_htab_dwords(D, H, W, usd, hslo) : 0;
+        htab = hw_dw ? Workspace::get<uint32_t>(hw_dw) : nullptr;
+        launch_cross_arms2(2, pk, u, d, l, r, ucd, lcd, usd, lsd, H, W, pre ? wide : nullptr, htab);
     }
     // with refinement the raw WTA maps live in scratch and the bilateral filter, the last step, writes the caller's buffers
     float *wl = refine ? Workspace::get<float>(HW) : d_disp_l, *wr = refine ? Workspace::get<float>(HW) : d_disp_r;
@@ -709,7 +713,7 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
         const uint32_t *pk[2] = {pk_l, pk_r}, *cn[2] = {cen[0], cen[1]};
         const u8 *u[2] = {al.up, ar.up}, *d[2] = {al.down, ar.down}, *l[2] = {al.left, ar.left}, *r[2] = {al.right, ar.right};
         float *dv[2] = {wl, wr};
-        launch_aggm_frame(pk, cn, rho_table(ad_coeff, census_coeff), va, vb, u, d, l, r, dv, D, zero_disp, H, W, usd, hslo);
+        launch_aggm_frame(pk, cn, rho_table(ad_coeff, census_coeff), va, vb, u, d, l, r, dv, D, zero_disp, H, W, usd, hslo, htab);
         if (hslo) launch_hslo_wta_pq(2, vb, va, hs_a, hs_b, hs_sign, dv, 15.0f, 1.0f, 3.0f, D, zero_disp, H, W, elem_sz);
     } else if (hslo) {
         core_agg(cl, sc, al, D, H, W, usd);
@@ -796,7 +800,7 @@ void stm_d_adcensus_stm(unsigned char *d_img_sbs, float *d_disp_l, float *d_disp
     const int H = num_rows, W = num_cols, N = num_views;
     const size_t HW = (size_t)H * W, IMG = HW * elem_sz;
     const size_t V = pq_volume_floats(num_disp, H, W); // >= the quad-interleaved volume of the HSLO / legacy paths
-    Workspace::begin(((stages & 0x100) ? 13 : 4) * V * 4 + (size_t)(N + 2) * IMG + 128 * HW + (1u << 20));
+    Workspace::begin(((stages & 0x100) ? 13 : 4) * V * 4 + (size_t)(N + 2) * IMG + 168 * HW + (1u << 20));
     u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
     uint32_t *pre[4] = {nullptr, nullptr, nullptr, nullptr};
     const bool fused_split = num_cols_sbs >= 2 * W; // both halves complete: emit the derived pixel formats in the same pass
@@ -833,7 +837,7 @@ void stm_d_adcensus_stm_2(unsigned char *d_img_sbs, float *d_disp_l, float *d_di
     const int H = num_rows, W = num_cols, h = num_rows_disp, w = num_cols_disp, N = num_views;
     const size_t HW = (size_t)H * W, IMG = HW * elem_sz, hw = (size_t)h * w;
     const size_t V = pq_volume_floats(num_disp, h, w);
-    Workspace::begin(4 * V * 4 + (size_t)(N + 4) * IMG + 96 * HW + 8 * hw + (1u << 20));
+    Workspace::begin(4 * V * 4 + (size_t)(N + 4) * IMG + 136 * HW + 8 * hw + (1u << 20));
     u8 *img_l = Workspace::get<u8>(IMG), *img_r = Workspace::get<u8>(IMG);
     launch_demux_sbs(img_l, img_r, d_img_sbs, H, num_cols_sbs, W, elem_sz);
     u8 *low_l = Workspace::get<u8>(hw * elem_sz), *low_r = Workspace::get<u8>(hw * elem_sz);

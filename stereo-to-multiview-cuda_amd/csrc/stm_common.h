@@ -143,7 +143,8 @@ int ref_quirks(); // stm_set_ref_quirks
 void launch_cross_arms(const uint32_t *packed, u8 *up, u8 *down, u8 *left, u8 *right,
                        float ucd, float lcd, int usd, int lsd, int H, int W);
 void launch_cross_arms2(int nviews, const uint32_t *const *packed, u8 *const *up, u8 *const *down, u8 *const *left,
-                        u8 *const *right, float ucd, float lcd, int usd, int lsd, int H, int W, const uint32_t *const *wide_ready = nullptr);
+                        u8 *const *right, float ucd, float lcd, int usd, int lsd, int H, int W, const uint32_t *const *wide_ready = nullptr,
+                        uint32_t *htab = nullptr); // htab: also build stm_k_pq_hsr's horizontal window table (aggh_table_dwords(nviews, H, W))
 void launch_agg_h(Vol in, Vol out, const u8 *armL, const u8 *armR, int D, int H, int W);
 void launch_agg_v(Vol in, Vol out, const u8 *armU, const u8 *armD, int D, int H, int W, int usd);
 void launch_agg_h2(Vol in_a, Vol out_a, const u8 *armL_a, const u8 *armR_a, Vol in_b, Vol out_b, const u8 *armL_b, const u8 *armR_b,
@@ -206,13 +207,18 @@ size_t pq_volume_floats(int D, int H, int W);
 bool aggm_supports(int usd, int H, int W);
 void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, const float *lut, float *const *vol_a, float *const *vol_b,
                        const u8 *const *armU, const u8 *const *armD, const u8 *const *armL, const u8 *const *armR, float *const *disp,
-                       int D, int zd, int H, int W, int usd, bool keep_volume = false);
+                       int D, int zd, int H, int W, int usd, bool keep_volume = false, uint32_t *htab_ready = nullptr);
+size_t aggm_frame_htab_dwords(int D, int H, int W, int usd, bool keep_volume);
 // ca_cross / d_ca_cross of one volume in the caller's layout on the matrix-pipe kernels; `out` may be `in`.  Returns false, with
 // `out` untouched, when the volume holds an infinite, NaN or denormal element (one host read-back of a flag): the caller runs
 // the vector-ALU kernels instead.  aggm_stage_bytes: what it carves from the current Workspace scope.
 bool launch_aggm_stage(Vol in, Vol out, const u8 *armU, const u8 *armD, const u8 *armL, const u8 *armR, int D, int H, int W, int usd);
 size_t aggm_stage_bytes(int D, int H, int W, int usd);
 // both vertical passes with a strip's rows in registers (stm_kernels_aggv.hip); `tab` / `rec`: the table of stm_k_vwin_table
+bool aggh_supports(int usd, int D); // stm_kernels_aggh.hip: last horizontal pass + WTA with the row's window range in registers
+size_t aggh_table_dwords(int nviews, int H, int W);
+void launch_hwin_table(PQViews &v, int nviews, uint32_t *tab, int H, int W); // (the frame path builds the table inside stm_k_cross_arms: launch_cross_arms2's htab)
+void launch_pq_hsr(PQViews &v, int nviews, const uint32_t *tab, int D, int zd, int H, int W);
 bool aggv_supports(int usd);
 int aggv_table_top();
 int aggv_table_rec();

@@ -20,7 +20,7 @@
 //   H pass: one block = one image row x QPB disparity quads; the whole row lives in LDS (W * 16 B).
 //   V pass: one block = a strip of VTX columns x a band of rows x one quad; rows stream top to bottom
 //           through an LDS ring, each input row is read from HBM exactly once per band (+ usd halo).
-#include "stm_common.h"
+#include "stm_hwin.h"
 
 namespace stm {
 
@@ -59,13 +59,16 @@ __global__ __launch_bounds__(256) void stm_k_widen_px(const uint32_t *__restrict
 struct ArmsArgs {
     const uint32_t *img[2]; // wide pixels
     u8 *up[2], *down[2], *left[2], *right[2];
+    uint32_t *htab; // HTAB: the horizontal window table of stm_k_pq_hsr, records of view 0 then view 1 (stm_hwin.h)
 };
 
+template <bool HTAB>
 __global__ __launch_bounds__(256) void stm_k_cross_arms(ArmsArgs a, uint32_t tg_far, uint32_t tg_near, int usd, int lsd, int H, int W)
 {
     const int v = blockIdx.z;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
+    const int xr = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (HTAB ? (xr & ~63) >= W : xr >= W) return; // HTAB: whole waves only (no block-wide barrier below)
+    const int x = min(xr, W - 1); // HTAB: a lane past the row stays for the table's cross-lane steps (it repeats the last pixel, stores nothing)
     const int p = y * W + x;
     const uint32_t *__restrict__ img = a.img[v];
     const uint32_t anchor = img[p];
@@ -130,10 +133,17 @@ __global__ __launch_bounds__(256) void stm_k_cross_arms(ArmsArgs a, uint32_t tg_
         }
     }
 #undef STM_ARM_LOADS
-    a.up[v][p] = (u8)arm[0];
-    a.down[v][p] = (u8)arm[1];
-    a.left[v][p] = (u8)arm[2];
-    a.right[v][p] = (u8)arm[3];
+    if (xr < W) {
+        a.up[v][p] = (u8)arm[0];
+        a.down[v][p] = (u8)arm[1];
+        a.left[v][p] = (u8)arm[2];
+        a.right[v][p] = (u8)arm[3];
+    }
+    if (HTAB) {
+        __shared__ uint32_t ev_all[4][4 * 96];
+        const int nTx = (W + 15) >> 4;
+        hwin_build(a.htab + (size_t)v * H * nTx * HR_REC, ev_all[threadIdx.x >> 6], y, blockIdx.x * 256 + (threadIdx.x & ~63), arm[2], arm[3], W, nTx);
+    }
 }
 
 // threshold as the integer t with (int diff > threshold) <=> (diff > t), clamped to [-1, 255], times the field pattern
@@ -149,7 +159,8 @@ static uint32_t wide_threshold(float t)
 
 // nviews = 1 or 2: both views of a frame share the launch.  packed[] = BGRX planes (launch_pack_bgrx).
 void launch_cross_arms2(int nviews, const uint32_t *const *packed, u8 *const *up, u8 *const *down, u8 *const *left,
-                        u8 *const *right, float ucd, float lcd, int usd, int lsd, int H, int W, const uint32_t *const *wide_ready)
+                        u8 *const *right, float ucd, float lcd, int usd, int lsd, int H, int W, const uint32_t *const *wide_ready,
+                        uint32_t *htab)
 {
     ArmsArgs a;
     const int n = H * W;
@@ -170,8 +181,13 @@ void launch_cross_arms2(int nviews, const uint32_t *const *packed, u8 *const *up
         a.img[v] = wide[s]; a.up[v] = up[s]; a.down[v] = down[s]; a.left[v] = left[s]; a.right[v] = right[s];
     }
     if (usd > 255) usd = 255; // arms are stored as u8 (reference T2)
-    STM_LAUNCH(stm_k_cross_arms, dim3(cdiv(W, 256), H, nviews), dim3(256), 0, stream(), a, wide_threshold(ucd),
-                       wide_threshold(lcd), usd, lsd, H, W);
+    a.htab = htab;
+    if (htab && usd <= HR_TOP) // (longer arms than the table's range: the caller does not ask for it, aggh_supports)
+        STM_LAUNCH(stm_k_cross_arms<true>, dim3(cdiv(W, 256), H, nviews), dim3(256), 0, stream(), a, wide_threshold(ucd),
+                           wide_threshold(lcd), usd, lsd, H, W);
+    else
+        STM_LAUNCH(stm_k_cross_arms<false>, dim3(cdiv(W, 256), H, nviews), dim3(256), 0, stream(), a, wide_threshold(ucd),
+                           wide_threshold(lcd), usd, lsd, H, W);
     STM_CHECK_LAUNCH();
 }
 

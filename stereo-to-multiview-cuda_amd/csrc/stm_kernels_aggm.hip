@@ -1141,7 +1141,8 @@ void launch_from_pq(const float *pq, Vol out, int D, int H, int W)
 // The aggregation chain on PQ volumes for `nviews` views (1 or 2).
 //   from_costs: the first horizontal pass computes the initial costs itself (images -> vol_b), else it reads vol_a;
 //   then both vertical passes (vol_b -> vol_a); then the last horizontal pass, vol_a -> disparities (wta) or -> vol_b.
-static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const float *lut, int D, int zd, int H, int W, int usd)
+static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const float *lut, int D, int zd, int H, int W, int usd,
+                       uint32_t *htab_ready = nullptr)
 {
     const int G = (W + 3) / 4, NC = (D + 15) / 16;
     if (usd > 255) usd = 255;
@@ -1156,6 +1157,29 @@ static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const 
     const bool fuse_cost = from_costs && (agg_variant() / 1000000) % 10 != 1; // 1: separate stm_k_pq_cost + volume-reading first pass
     const int spl = nseg > 24 ? cdiv(nseg, 16) : 1; // blocks per image row of the streaming passes
     const bool streaming = NG / 4 >= NW && (agg_variant() / 10) % 10 != 1 && (NC <= 4 || (agg_variant() / 10) % 10 != 2); // the ring is at least one segment long; 20: D > 64 on the block-per-segment kernels as before
+    // The window tables of the vertical passes and of the last horizontal pass depend on the arms only; they are built once
+    // per call for all views (the horizontal one already by stm_k_cross_arms when the caller passes htab_ready)
+    constexpr int NTP = 3, TS = 16 * NTP; // stm_k_pq_v12t: 2 and 4 tiles per pass and step: 0.729 ms each against 0.679
+    const int UQ = (usd + 3) & ~3, nT = (H + 15) / 16;
+    const bool regs = aggv_supports(usd) && (agg_variant() / 10000000) % 10 != 1; // round 4: a strip's rows in registers (stm_kernels_aggv.hip); 10000000: the LDS-ring kernel
+    const int rec = regs ? aggv_table_rec() : 8 + 8 * ((2 * usd + 21) / 4 + 2); // header + the longest sweep + one quad of read-ahead
+    const int LAG = (UQ + TS - 1) / TS + 1;
+    const int RQ1 = (TS + 2 * UQ) / 4, RQ2 = (TS * (LAG + 1) + UQ) / 4;
+    uint32_t *vtab = Workspace::get<uint32_t>((size_t)nviews * nT * G * rec);
+    // round 4: the row's window range in registers (stm_kernels_aggh.hip); 100000000: the LDS row walk stm_k_pq_hs
+    const bool hregs = wta && aggh_supports(usd, D) && (agg_variant() / 100000000) % 10 != 1;
+    uint32_t *htab = !hregs ? nullptr : htab_ready ? htab_ready : Workspace::get<uint32_t>(aggh_table_dwords(nviews, H, W));
+    {
+        {
+            ProfScope p("pq_vtab");
+            STM_LAUNCH(stm_k_vwin_table, dim3(cdiv(G, 4), nT, nviews), dim3(256), 0, stream(), v, vtab, rec, H, W, G, nT, regs ? aggv_table_top() : -1);
+            STM_CHECK_LAUNCH();
+        }
+        if (hregs && !htab_ready) {
+            ProfScope p("pq_htab");
+            launch_hwin_table(v, nviews, htab, H, W);
+        }
+    }
     if (from_costs && !fuse_cost) {
         ProfScope p("pq_cost");
         const size_t smem = (size_t)(2 * PC_TX + 2 * (PC_TX + 2 * pad) + 768 + 72) * 4;
@@ -1199,32 +1223,22 @@ static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const 
         STM_CHECK_LAUNCH();
     }
     {
-        // fused vertical kernel; the window table is built once per call for all views
-        constexpr int NTP = 3, TS = 16 * NTP; // 2 and 4 tiles per pass and step: 0.729 ms each against 0.679
-        const int UQ = (usd + 3) & ~3, nT = (H + 15) / 16;
-        const bool regs = aggv_supports(usd) && (agg_variant() / 10000000) % 10 != 1; // round 4: a strip's rows in registers (stm_kernels_aggv.hip); 10000000: the LDS-ring kernel
-        const int rec = regs ? aggv_table_rec() : 8 + 8 * ((2 * usd + 21) / 4 + 2); // header + the longest sweep + one quad of read-ahead
-        const int LAG = (UQ + TS - 1) / TS + 1;
-        const int RQ1 = (TS + 2 * UQ) / 4, RQ2 = (TS * (LAG + 1) + UQ) / 4;
-        uint32_t *tab = Workspace::get<uint32_t>((size_t)nviews * nT * G * rec);
-        {
-            ProfScope p("pq_vtab");
-            STM_LAUNCH(stm_k_vwin_table, dim3(cdiv(G, 4), nT, nviews), dim3(256), 0, stream(), v, tab, rec, H, W, G, nT, regs ? aggv_table_top() : -1);
-            STM_CHECK_LAUNCH();
-        }
+        // fused vertical kernel
         ProfScope p("pq_v12");
         if (regs) {
-            launch_pq_v12r(v, nviews, tab, rec, H, W, G, NC);
+            launch_pq_v12r(v, nviews, vtab, rec, H, W, G, NC);
         } else {
             const size_t smem = (size_t)(RQ1 + RQ2) * 1024;
             allow_lds_m((const void *)stm_k_pq_v12t<NTP>, smem);
-            STM_LAUNCH(stm_k_pq_v12t<NTP>, dim3(G, NC, nviews), dim3(128 * NTP), smem, stream(), v, tab, rec, H, W, G, NC, UQ, RQ1, RQ2, LAG, dbgh);
+            STM_LAUNCH(stm_k_pq_v12t<NTP>, dim3(G, NC, nviews), dim3(128 * NTP), smem, stream(), v, vtab, rec, H, W, G, NC, UQ, RQ1, RQ2, LAG, dbgh);
             STM_CHECK_LAUNCH();
         }
     }
     {
         ProfScope p("pq_hw");
-        if (streaming && !wta) {
+        if (hregs) {
+            launch_pq_hsr(v, nviews, htab, D, zd, H, W);
+        } else if (streaming && !wta) {
             allow_lds_m((const void *)stm_k_pq_hs<NW, false>, smem_h);
             STM_LAUNCH((stm_k_pq_hs<NW, false>), dim3(nviews * H * spl), dim3(64 * NW), smem_h, stream(), v, D, zd, H, W, G, NC, HG, nseg, spl, dbgh);
         } else if (streaming) {
@@ -1247,16 +1261,24 @@ static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const 
 
 // cost -> H -> V, V -> H + WTA for both views of a frame.  vol_a / vol_b: two PQ volumes per view (pq_volume_floats each).
 // keep_volume: the last pass writes the aggregated costs to vol_b instead of doing WTA (the HSLO stage follows; disp unused).
+// htab_ready: the horizontal window table of both views (aggm_frame_htab_dwords) already built by launch_cross_arms2, or nullptr.
+// aggm_frame_htab_dwords: its size when this frame's last pass will use it, else 0.
+size_t aggm_frame_htab_dwords(int D, int H, int W, int usd, bool keep_volume)
+{
+    if (usd > 255) usd = 255;
+    const bool hregs = !keep_volume && aggh_supports(usd, D) && (agg_variant() / 100000000) % 10 != 1;
+    return hregs && (agg_variant() / 1000000000) % 10 != 1 ? aggh_table_dwords(2, H, W) : 0; // 1000000000: the stand-alone table kernel
+}
 void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, const float *lut, float *const *vol_a, float *const *vol_b,
                        const u8 *const *armU, const u8 *const *armD, const u8 *const *armL, const u8 *const *armR, float *const *disp,
-                       int D, int zd, int H, int W, int usd, bool keep_volume)
+                       int D, int zd, int H, int W, int usd, bool keep_volume, uint32_t *htab_ready)
 {
     PQViews v;
     for (int i = 0; i < 2; ++i) {
         v.pk[i] = pk[i]; v.cen[i] = cen[i]; v.a[i] = vol_a[i]; v.b[i] = vol_b[i];
         v.armU[i] = armU[i]; v.armD[i] = armD[i]; v.armL[i] = armL[i]; v.armR[i] = armR[i]; v.disp[i] = disp[i];
     }
-    aggm_chain(v, 2, true, !keep_volume, lut, D, zd, H, W, usd);
+    aggm_chain(v, 2, true, !keep_volume, lut, D, zd, H, W, usd, htab_ready);
 }
 
 // The per-stage aggregation (ca_cross / d_ca_cross, d_ca_cross.cu:255-270) of ONE volume in the caller's layout on the

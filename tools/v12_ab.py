@@ -49,7 +49,7 @@ for v in variants:
     for _ in range(5): dev.d_adcensus_stm(d_sbs, dl_, dr_, out_, p, stages=3)
     torch.cuda.synchronize()
     dev.prof_enable(False)
-    for name in ("pq_cost", "pq_h", "pq_vtab", "pq_v12", "pq_hw", "cross_arms", "irv", "bilateral"):
+    for name in ("pq_cost", "pq_h", "pq_vtab", "pq_v12", "pq_htab", "pq_hw", "cross_arms", "irv", "bilateral"):
         n, ms = dev.prof_read(name)
         if n: print("   %-12s %3d launches, avg %.4f ms" % (name, n, ms / n), flush=True)
 sys.exit(1 if bad else 0)
