@@ -9,6 +9,7 @@
 // All of them are image-sized (<= 17 B/px of HBM traffic) and LDS/latency bound; accumulation orders
 // follow the reference loops exactly (row-major taps, sequential float adds, no contraction).
 #include "stm_common.h"
+#include <type_traits>
 #include <mutex>
 
 #include <map>
@@ -553,6 +554,311 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote(IrvArgs a, int i
     }
 }
 
+// ------------------------------------------------------------------ round 4: column runs
+// profiles/r04_pmc_irv.txt: on real image content the vote kernel is bound by its vector instructions (60 % of the SIMD-cycles of a
+// launch), about 380 per listed outlier, half of them the walk over the ~36 rows of its cross region.  But the row segments of a
+// region depend on the COLUMN only (row q contributes [x - armL(q, x), x + armR(q, x)], d_dr_irv.cu:186-199), so two outliers of
+// one column share every row their vertical arms have in common -- and 88 % of the listed outliers have a listed outlier directly
+// above them whose row range differs by 2.2 rows in the mean (tools/irv_stats.py: 5.7 M region rows per iteration, 0.5 M when
+// each outlier starts from the histogram of the one above).  So:
+//  * stm_k_irv_compact_cm lists the outliers tile by tile (64 x 64 pixels), COLUMN-major inside a tile;
+//  * stm_k_irv_vote_cm gives a wave a few consecutive entries: it keeps the histogram of the last region it counted and, for
+//    the next entry of the same column, removes the rows that left the range and adds the rows that entered it (one pass over at
+//    most 64 such rows, each with its sign); anything else (another column, no overlap) is counted from scratch.
+// Everything else -- flags in the list entries, the two code planes, dirty tiles, the accept rule -- is stm_k_irv_vote's.
+constexpr int IVC_CH = 16; // most list entries per wave and trip (fewer when the list is short: the chip wants many more waves than it holds)
+
+__global__ __launch_bounds__(IC_T) void stm_k_irv_compact_cm(IrvArgs a, uint32_t HW, int zd, int nb, int H, int W, int usd, float thresh_h, int thresh_s, int tiles_x)
+{
+    __shared__ int s_tot[IC_T / 64];
+    __shared__ int s_base;
+    __shared__ uint32_t s_flag[64][16]; // per pixel of the tile one byte: 0 = not listed, 1 = listed, 2 = listed, not in the first iteration
+    const int v = blockIdx.y;
+    const u8 *__restrict__ outl = a.outl[v];
+    const float *__restrict__ disp = a.disp[v];
+    uint32_t *__restrict__ list = a.list[v];
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+    const int gy = ty * 64 + r, gx0 = tx * 64 + c4;
+    const uint32_t p = (uint32_t)gy * (uint32_t)W + (uint32_t)gx0;
+    const int nvalid = gy < H ? min(max(W - gx0, 0), 4) : 0; // pixels of this thread inside the image
+    uint32_t w = 0;
+    // the same pass packs (outlier flag, disparity) into the 16-bit vote code the vote kernel reads
+    if (nvalid == 4 && (W & 3) == 0 && ((((uintptr_t)outl) & 3) | (((uintptr_t)disp) & 15)) == 0) {
+        w = *(const uint32_t *)(outl + p);
+        const float4 d = *(const float4 *)(disp + p);
+        const uint32_t c0 = irv_code((u8)(w & 0xff), d.x, zd, nb), c1 = irv_code((u8)((w >> 8) & 0xff), d.y, zd, nb);
+        const uint32_t c2 = irv_code((u8)((w >> 16) & 0xff), d.z, zd, nb), c3 = irv_code((u8)(w >> 24), d.w, zd, nb);
+        const uint2 cc = make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
+        *(uint2 *)(a.code[v][0] + p) = cc; // the code planes are workspace memory: aligned
+        *(uint2 *)(a.code[v][1] + p) = cc;
+    } else {
+        for (int j = 0; j < nvalid; ++j) {
+            const u8 o = outl[p + j];
+            w |= (uint32_t)o << (8 * j);
+            a.code[v][0][p + j] = a.code[v][1][p + j] = irv_code(o, disp[p + j], zd, nb);
+        }
+    }
+    const uint32_t *__restrict__ vp = a.vp[v];
+    uint32_t later = 0; // bit j: pixel p + j cannot be accepted in the first iteration (S0 <= thresh_s, d_dr_irv.cu:35)
+    if (vp != nullptr && w != 0) { // outliers that can never be accepted are not listed (see stm_k_irv_rowcount)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (((w >> (8 * j)) & 0xff) && j < nvalid) {
+                const int q = (int)p + j, gx = gx0 + j;
+                int cu = a.aU[v][q], cd = a.aD[v][q];
+                if (cu > usd) cu = usd;   // the clamps of the vote kernel (d_dr_irv.cu:179-180)
+                cu = min(cu, gy);
+                cd = min(cd, H - 1 - gy);
+                const int s0 = (int)(vp[(size_t)(gy + cd + 1) * W + gx] - vp[(size_t)(gy - cu) * W + gx]);
+                const int nmax = max(nb - 1, (int)disp[q] + zd);
+                if (s0 > 0 && !((float)nmax / (float)s0 > thresh_h)) w &= ~(0xffu << (8 * j));
+                else if (s0 <= thresh_s) later |= 1u << j;
+            }
+    }
+    uint32_t fl = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if ((w >> (8 * j)) & 0xff) fl |= (((later >> j) & 1u) ? 2u : 1u) << (8 * j);
+    s_flag[r][c4 >> 2] = fl;
+    __syncthreads();
+    // column-major: thread t takes rows 4 (t % 16) .. + 3 of column t / 16
+    const int col = threadIdx.x >> 4, r4 = (threadIdx.x & 15) * 4;
+    uint32_t f[4];
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[j] = (s_flag[r4 + j][col >> 2] >> (8 * (col & 3))) & 0xffu;
+        c += f[j] != 0;
+    }
+    int incl = c; // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_tot[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int i = 0; i < IC_T / 64; ++i) tot += s_tot[i];
+        s_base = tot ? atomicAdd(&a.counts[v][0], tot) : 0;
+    }
+    __syncthreads();
+    int k = s_base + incl - c;
+    for (int i = 0; i < wave; ++i) k += s_tot[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (f[j]) {
+            const uint32_t q = (uint32_t)(ty * 64 + r4 + j) * (uint32_t)W + (uint32_t)(tx * 64 + col);
+            if ((uint32_t)k < HW) list[k] = q | (f[j] == 2 ? IV_LATER : 0u); // the list holds HW entries: a counter that was not cleared can never write past it
+            else atomicOr(a.diag, 1u); // (never on the timed path)
+            ++k;
+        }
+}
+
+__global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote_cm(IrvArgs a, int it, int thresh_s, float thresh_h, int H, int W,
+                                                                   int nb, int zd, int usd, int tiles_x, int tiles_y, int tile_sh, int paper_ratio)
+{
+    extern __shared__ uint32_t irv_lds[]; // per wave: uint4 slots[nb + 1 + 64]: slot 0 = "other", 1 + b = bin b, then one per lane
+    const int v = blockIdx.y;
+    float *__restrict__ disp = a.disp[v];
+    const uint16_t *__restrict__ code_pl = a.code[v][it & 1];
+    uint16_t *__restrict__ code_nx = a.code[v][(it & 1) ^ 1];
+    const u8 *__restrict__ aL = a.aL[v], *__restrict__ aR = a.aR[v];
+    uint32_t *__restrict__ list = a.list[v];
+    const u8 *__restrict__ dirty = it > 0 ? a.dirty[v] + (size_t)(it - 1) * tiles_x * tiles_y : nullptr;
+    u8 *__restrict__ dirty_out = a.dirty[v] + (size_t)it * tiles_x * tiles_y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nslot = nb + 1 + 64;
+    uint32_t *hist = irv_lds + wave * nslot * 4;
+    const uint32_t nv_slot = (uint32_t)(nb + 1 + lane);                 // this lane's own no-vote slot
+    const uint32_t sub_addr = (uint32_t)((wave * nslot * 4 + (lane & 3)) * 4); // LDS byte address of copy lane % 4 of slot 0
+    const int n_raw = a.counts[v][0];
+    const int n = min(n_raw, H * W); // never past the list (capacity H W), whatever the counter holds
+    if (n_raw > H * W && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.diag, 2u);
+    const int chl = max(1, min(IVC_CH, n >> 14)); // entries per trip (1080p, real content: 5; 4 to 16 measured alike, 16 slower)
+    const int nchunks = (n + chl - 1) / chl, stride = gridDim.x * IV_WAVES;
+    const int HWi = H * W;
+    const int half4 = (lane >> 5) * 4, lw = lane & 31;
+    const uint32_t l2h = 2u * (uint32_t)lw, lane2 = 2u * lane;
+
+    // `cnt` rows (cnt <= 64, wave-uniform): lane r < cnt holds row yrow of column gx and the sign sg (+1 / -1) its pixels are
+    // counted with.  The row steps are stm_k_irv_vote's (two rows per step when every segment fits half a wave)
+    auto count_rows = [&](int gx, int yrow, int sg, int cnt) {
+        uint32_t roff = 0;
+        int rw = 0;
+        if (lane < cnt) {
+            const int q = yrow * W + gx;
+            const int cl = min((int)aL[q], gx);
+            rw = max(min(cl + (int)aR[q] + 1, W - (gx - cl)), 0);
+            roff = 2u * (uint32_t)(q - cl);
+        }
+        if (__ballot(rw > 32) == 0) {
+            auto steps = [&](auto U_) {
+                constexpr int U = decltype(U_)::value;
+                for (int j0 = 0; j0 < cnt; j0 += 2 * U) {
+                    uint32_t cdv[U];
+                    int wv[U], sv[U];
+                    const int sel = half4 + 4 * j0;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { // rows past cnt: their lanes hold offset 0 / width 0
+                        const uint32_t so = (uint32_t)__builtin_amdgcn_ds_bpermute(sel + 8 * u, (int)roff);
+                        wv[u] = __builtin_amdgcn_ds_bpermute(sel + 8 * u, rw);
+                        sv[u] = __builtin_amdgcn_ds_bpermute(sel + 8 * u, sg);
+                        cdv[u] = *(const uint16_t *)((const char *)code_pl + (so + l2h));
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t c = lw < wv[u] ? cdv[u] : IV_NOVOTE;
+                        const uint32_t slot = min(c, nv_slot);
+                        atomicAdd(irv_lds + ((slot * 16u + sub_addr) >> 2), (uint32_t)sv[u]);
+                    }
+                }
+            };
+            if (cnt <= 8) steps(std::integral_constant<int, 2>()); // (64 is a multiple of 2 U: no wrap of the lane index)
+            else steps(std::integral_constant<int, IV_U>());
+            return;
+        }
+        for (int j0 = 0; j0 < cnt; j0 += IV_U) {
+            uint32_t cdv[IV_U];
+#pragma unroll
+            for (int u = 0; u < IV_U; ++u) { // the first 64 pixels of IV_U rows: all loads issued before any is consumed
+                const uint32_t so = (uint32_t)__builtin_amdgcn_readlane((int)roff, (j0 + u) & 63); // rows past cnt: lanes hold 0 / width 0
+                cdv[u] = *(const uint16_t *)((const char *)code_pl + (so + lane2));
+            }
+#pragma unroll
+            for (int u = 0; u < IV_U; ++u) {
+                const int w = __builtin_amdgcn_readlane(rw, (j0 + u) & 63);
+                const int s1 = __builtin_amdgcn_readlane(sg, (j0 + u) & 63);
+                const uint32_t c = lane < w ? cdv[u] : IV_NOVOTE;
+                const uint32_t slot = min(c, nv_slot); // a vote (c <= nb) or this lane's own slot
+                atomicAdd(irv_lds + ((slot * 16u + sub_addr) >> 2), (uint32_t)s1);
+            }
+        }
+        if (__ballot(rw > 64) != 0) { // segments wider than 64 pixels (arm sum >= 64): rare
+            for (int j = 0; j < cnt; ++j) {
+                const int w = __builtin_amdgcn_readlane(rw, j);
+                const uint32_t so = (uint32_t)__builtin_amdgcn_readlane((int)roff, j);
+                const int s1 = __builtin_amdgcn_readlane(sg, j);
+                for (int c0 = 64; c0 < w; c0 += 64) {
+                    uint32_t c = IV_NOVOTE;
+                    if (c0 + lane < w) c = *(const uint16_t *)((const char *)code_pl + (so + 2u * (uint32_t)c0 + lane2));
+                    const uint32_t slot = min(c, nv_slot);
+                    atomicAdd(irv_lds + ((slot * 16u + sub_addr) >> 2), (uint32_t)s1);
+                }
+            }
+        }
+    };
+
+    for (int ch = blockIdx.x * IV_WAVES + wave; ch < nchunks; ch += stride) {
+        // the chunk's entries and their pixels' vertical arms and disparities: one gather each for the whole chunk
+        const int i0 = ch * chl;
+        uint32_t e_l = IV_DEAD;
+        int cu_l = 0, cd_l = 0;
+        float own_l = 0.f;
+        if (lane < chl && i0 + lane < n) {
+            e_l = list[i0 + lane];
+            const uint32_t q = e_l & ~(IV_ACCEPTED | IV_LATER);
+            if (q < (uint32_t)HWi) {
+                cu_l = a.aU[v][q];
+                cd_l = a.aD[v][q];
+                own_l = disp[q];
+            }
+        }
+        bool have = false; // the LDS histogram holds rows r0 .. r1 of column rx
+        int rx = 0, r0 = 0, r1 = 0;
+        for (int k = 0; k < chl && i0 + k < n; ++k) {
+            const int i = i0 + k;
+            const uint32_t entry = (uint32_t)__builtin_amdgcn_readlane((int)e_l, k);
+            if ((entry & ~(IV_ACCEPTED | IV_LATER)) >= (uint32_t)HWi) { // IV_DEAD, or not a pixel of this frame (stale memory behind a wrong counter)
+                if (entry != IV_DEAD && lane == 0) atomicOr(a.diag, 4u);
+                continue;
+            }
+            if ((entry & IV_LATER) && it == 0) continue; // S <= thresh_s in this iteration: rejected whatever the votes (the flag is ignored afterwards)
+            if (entry & IV_ACCEPTED) { // accepted by the previous launch: bring this launch's write plane up to date
+                if (lane == 0) {
+                    const uint32_t q = entry & ~IV_ACCEPTED;
+                    code_nx[q] = code_pl[q];
+                    list[i] = IV_DEAD;
+                }
+                continue;
+            }
+            const int p = (int)(entry & ~IV_LATER);
+            const int gy = p / W, gx = p - gy * W;
+            int cu = __builtin_amdgcn_readlane(cu_l, k), cd = __builtin_amdgcn_readlane(cd_l, k);
+            const float own = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, own_l), k));
+            if (cu > usd) cu = usd;   // d_dr_irv.cu:179-180
+            cu = min(cu, gy);         // arms built by ca_cross never leave the image; these two clamps only keep a
+            cd = min(cd, H - 1 - gy); // caller who passes inconsistent arms from reading outside the planes
+            if (dirty) { // bounding box of the region = [gx-usd, gx+usd] x [gy-cu, gy+cd]: at most 8x8 tiles (launch_irv picks the tile size)
+                const int tx0 = max(gx - usd, 0) >> tile_sh, tx1 = min(gx + usd, W - 1) >> tile_sh;
+                const int ty0 = (gy - cu) >> tile_sh, ty1 = (gy + cd) >> tile_sh;
+                const int nx = tx1 - tx0 + 1, nt = nx * (ty1 - ty0 + 1);
+                int d = nt > 64; // more tiles than lanes (cannot happen with launch_irv's tile size): do not prune
+                if (lane < nt) d = dirty[(ty0 + lane / nx) * tiles_x + tx0 + lane % nx];
+                if (__ballot(d != 0) == 0) continue; // same region contents as last time -> same vote -> rejected again
+            }
+            const int t0 = gy - cu, t1 = gy + cd; // rows t0 .. t1 inclusive (SURVEY A-Q17 iii)
+            const int nrows = t1 - t0 + 1;
+            // rows that leave / enter the range when the histogram of rows r0 .. r1 of this column is kept
+            const int rem_top = max(min(t0, r1 + 1) - r0, 0), add_top = max(min(r0, t1 + 1) - t0, 0);
+            const int rem_bot = max(r1 - max(t1, r0 - 1), 0), add_bot = max(t1 - max(r1, t0 - 1), 0);
+            const int nd = rem_top + add_top + rem_bot + add_bot;
+            if (have && gx == rx && max(t0, r0) <= min(t1, r1) && nd < nrows && nd <= 64) {
+                if (nd > 0) {
+                    int yrow = 0, sg = 0, j = lane;
+                    if (j < rem_top) { yrow = r0 + j; sg = -1; }
+                    else if ((j -= rem_top) < add_top) { yrow = t0 + j; sg = 1; }
+                    else if ((j -= add_top) < rem_bot) { yrow = t1 + 1 + j; sg = -1; }
+                    else if ((j -= rem_bot) < add_bot) { yrow = r1 + 1 + j; sg = 1; }
+                    count_rows(gx, yrow, sg, nd);
+                }
+            } else {
+                for (int sl = lane; sl <= nb; sl += 64) *(uint4 *)(hist + sl * 4) = make_uint4(0, 0, 0, 0); // the per-lane slots are never read
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int jb = 0; jb < nrows; jb += 64) count_rows(gx, t0 + jb + lane, 1, min(nrows - jb, 64));
+            }
+            have = true; rx = gx; r0 = t0; r1 = t1;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // first bin with the strictly largest count (d_dr_irv.cu:206-215): max over (count, -bin); S = all reliable pixels
+            uint32_t key = 0, tot = 0;
+            for (int sl = lane; sl <= nb; sl += 64) {
+                const uint4 h4 = *(const uint4 *)(hist + sl * 4);
+                const uint32_t c = h4.x + h4.y + h4.z + h4.w;
+                tot += c;
+                const uint32_t kk = (c << 16) | (uint32_t)(0xFFFF - (sl - 1));
+                if (sl > 0 && c != 0 && kk > key) key = kk;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            key = wave_max_u32(key);
+            const int total = (int)wave_sum_u32(tot);
+            int max_d = (int)own; // default: own disparity (d_dr_irv.cu:182)
+            if (key != 0) max_d = (0xFFFF - (int)(key & 0xFFFF)) - zd;
+            // apply (d_dr_irv.cu:32-41): the ratio uses the winning BIN INDEX, not its count (:36, SURVEY A-Q17 iv)
+            const float num = paper_ratio ? (float)(key >> 16) : (float)(max_d + zd);
+            if (total > thresh_s && num / (float)total > thresh_h) {
+                const uint16_t nc = irv_code(0, (float)max_d, zd, nb);
+                if (lane == 0) {
+                    a.outl[v][p] = 0;
+                    disp[p] = (float)max_d;
+                    code_nx[p] = nc;
+                    dirty_out[(gy >> tile_sh) * tiles_x + (gx >> tile_sh)] = 1; // same value from every writer
+                    list[i] = (uint32_t)p | IV_ACCEPTED;
+                }
+            } else if (!paper_ratio && total > 0 && !((float)max(nb - 1, (int)own + zd) / (float)total > thresh_h)) {
+                // S only grows and the numerator never exceeds this bound (see stm_k_irv_rowcount): rejected now = rejected for good
+                if (lane == 0) list[i] = IV_DEAD;
+            }
+        }
+    }
+}
+
 void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const *up, const u8 *const *down,
                 const u8 *const *left, const u8 *const *right, int thresh_s, float thresh_h, int H, int W, int D, int zd,
                 int usd, int iterations, bool device_flavour)
@@ -614,8 +920,16 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
                    nviews == 2 ? vp[1] : vp[0], H, W);
         STM_CHECK_LAUNCH();
     }
-    STM_LAUNCH(stm_k_irv_compact, dim3((unsigned)((HW + 4 * IC_T - 1) / (4 * IC_T)), nviews), dim3(IC_T), 0, stream(), a, (uint32_t)HW, zd,
-                       nb, H, W, usd, thresh_h, thresh_s);
+    // round 4: the list column-major inside 64 x 64 tiles, a wave votes for runs of a column incrementally; 300: the raster list of round 3
+    const bool runs = (agg_variant() / 100) % 10 != 3;
+    if (runs) {
+        const int t64x = cdiv(W, 64), t64y = cdiv(H, 64);
+        STM_LAUNCH(stm_k_irv_compact_cm, dim3((unsigned)(t64x * t64y), nviews), dim3(IC_T), 0, stream(), a, (uint32_t)HW, zd, nb, H, W, usd, thresh_h,
+                   thresh_s, t64x);
+    } else {
+        STM_LAUNCH(stm_k_irv_compact, dim3((unsigned)((HW + 4 * IC_T - 1) / (4 * IC_T)), nviews), dim3(IC_T), 0, stream(), a, (uint32_t)HW, zd,
+                           nb, H, W, usd, thresh_h, thresh_s);
+    }
     STM_CHECK_LAUNCH();
     const size_t smem = (size_t)(nb + 1 + 64) * 16 * IV_WAVES; // per wave: four copies of (other, nb bins), one slot per lane
     // Several times more waves than the chip holds (1080p: 8100 blocks of 2 waves per view for 8192 wave slots): the waves walk
@@ -624,8 +938,12 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
     // with 8100 blocks of 2 waves 0.29 (16384 blocks of 4: 0.32; single-wave blocks: no further gain)
     const int iv_blocks = (int)std::min<size_t>(std::max<size_t>((HW + IV_PX_PER_BLOCK - 1) / IV_PX_PER_BLOCK, 256), 32768);
     for (int it = 0; it < rounds; ++it) {
-        STM_LAUNCH(stm_k_irv_vote, dim3(iv_blocks, nviews), dim3(64 * IV_WAVES), smem, stream(), a, it, thresh_s, thresh_h, H,
-                           W, nb, zd, usd, tiles_x, tiles_y, tile_sh, irv_paper_ratio());
+        if (runs)
+            STM_LAUNCH(stm_k_irv_vote_cm, dim3(iv_blocks, nviews), dim3(64 * IV_WAVES), smem, stream(), a, it, thresh_s, thresh_h, H,
+                               W, nb, zd, usd, tiles_x, tiles_y, tile_sh, irv_paper_ratio());
+        else
+            STM_LAUNCH(stm_k_irv_vote, dim3(iv_blocks, nviews), dim3(64 * IV_WAVES), smem, stream(), a, it, thresh_s, thresh_h, H,
+                               W, nb, zd, usd, tiles_x, tiles_y, tile_sh, irv_paper_ratio());
         STM_CHECK_LAUNCH();
     }
 }

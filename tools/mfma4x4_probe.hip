@@ -28,7 +28,7 @@ template <int F> __global__ __launch_bounds__(256) void k_rate(float *out, int i
     float a0 = 1.f, a1 = 1.f;
     const float b0 = b;
     int ridx = 0;
-    if (F == 3) asm volatile("s_set_gpr_idx_on %0, 0x2" : : "s"(0));
+    if (F >= 3) asm volatile("s_set_gpr_idx_on %0, 0x2" : : "s"(0));
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { // 4 x 16 MFMAs per iteration
@@ -45,6 +45,20 @@ template <int F> __global__ __launch_bounds__(256) void k_rate(float *out, int i
                     if ((k & 3) == 2) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0 cbsz:4 abid:%3" : "+v"(c2) : "v"(a0), "v"(b0), "n"(k));
                     if ((k & 3) == 3) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0 cbsz:4 abid:%3" : "+v"(c3) : "v"(a0), "v"(b0), "n"(k));
                 }
+                if (F >= 4) { // blocks of 4 (F = 4, 6) or 8 (F = 5) MFMAs, A shared by four MFMAs (cbsz:2), one v_cndmask per four
+                    const int blk = F == 5 ? 8 : 4;
+                    if (F == 6 && (k % blk) == 0) asm volatile("s_set_gpr_idx_idx %0" : : "s"(0));
+                    if ((k >> 2) & 1) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0 cbsz:2 abid:%3" : "+v"(c0) : "v"(a1), "v"(b0), "n"(k & 3));
+                    else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0 cbsz:2 abid:%3" : "+v"(c0) : "v"(a0), "v"(b0), "n"(k & 3));
+                    if ((k & 3) == 0) {
+                        if ((k >> 2) & 1) asm volatile("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(a0) : "s"(m));
+                        else asm volatile("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(a1) : "s"(m));
+                    }
+                    if ((k % blk) == 1) {
+                        if (F == 6) asm volatile("s_add_u32 %0, %0, 4\n\ts_cmp_eq_u32 %0, 88\n\ts_cselect_b32 %0, 0, %0" : "+s"(ridx) : : "scc");
+                        else asm volatile("s_add_u32 m0, m0, 0\n\ts_cmp_eq_u32 m0, 88\n\ts_cselect_b32 m0, 0x2000, m0" : : : "scc");
+                    }
+                }
                 if (F == 3) {
                     if ((k & 3) == 0) asm volatile("s_set_gpr_idx_idx %0" : : "s"(0));
                     if (q & 1) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0 cbsz:4 abid:%3" : "+v"(c0) : "v"(a1), "v"(b0), "n"(k));
@@ -58,7 +72,7 @@ template <int F> __global__ __launch_bounds__(256) void k_rate(float *out, int i
             }
         }
     }
-    if (F == 3) asm volatile("s_set_gpr_idx_off");
+    if (F >= 3) asm volatile("s_set_gpr_idx_off");
     asm volatile("s_nop 15" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
     float s = (float)ridx;
     for (int i = 0; i < 4; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
@@ -103,5 +117,8 @@ int main()
     run<1>(dout, "two independent accumulators, alternating");
     run<2>(dout, "four independent accumulators");
     run<3>(dout, "one chain + cndmask per 16 + ring index update per 4, index mode");
+    run<6>(dout, "cbsz:2, per 4 MFMAs: cndmask, s_set_gpr_idx_idx + 3 scalar");
+    run<4>(dout, "cbsz:2, per 4 MFMAs: cndmask, 3 scalar on M0 directly");
+    run<5>(dout, "cbsz:2, per 8 MFMAs: 2 cndmask, 3 scalar on M0 directly");
     return 0;
 }
