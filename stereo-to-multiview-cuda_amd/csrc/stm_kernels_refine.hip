@@ -163,11 +163,15 @@ __global__ __launch_bounds__(256) void stm_k_irv_clear(int *__restrict__ words, 
 //   stm_k_irv_colprefix: vp[y][x]  = cnt[0][x] + .. + cnt[y - 1][x];  S0(y, x) = vp[y + armD + 1][x] - vp[y - armU][x].
 // The compaction kernel then lists only the outliers that can still be accepted.
 constexpr int IRC_W = 4; // waves per image row: each takes a quarter of the row (a one-wave block walked the row in eight dependent trips)
-__global__ __launch_bounds__(64 * IRC_W) void stm_k_irv_rowcount(IrvArgs a, uint16_t *__restrict__ cnt0, uint16_t *__restrict__ cnt1, int H, int W)
+// `words` / `nwords`: the counters and dirty bytes of the call, cleared here (what stm_k_irv_clear does when there is no pruning pass;
+// nothing reads them before stm_k_irv_compact)
+__global__ __launch_bounds__(64 * IRC_W) void stm_k_irv_rowcount(IrvArgs a, uint16_t *__restrict__ cnt0, uint16_t *__restrict__ cnt1, int H, int W,
+                                                                 int *__restrict__ words, int nwords)
 {
     extern __shared__ uint32_t rp[]; // rp[x] = reliable pixels of this row in columns < x, x in [0, W]
     __shared__ int s_tot[IRC_W];
     const int v = blockIdx.y, y = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * (64 * IRC_W) + threadIdx.x; i < nwords; i += gridDim.x * gridDim.y * (64 * IRC_W)) words[i] = 0;
     const u8 *__restrict__ outl = a.outl[v];
     const u8 *__restrict__ aL = a.aL[v], *__restrict__ aR = a.aR[v];
     uint16_t *__restrict__ cnt = (v ? cnt1 : cnt0) + (size_t)y * W;
@@ -652,7 +656,7 @@ __global__ __launch_bounds__(IC_T) void stm_k_irv_compact_cm(IrvArgs a, uint32_t
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (f[j]) {
-            const uint32_t q = (uint32_t)(ty * 64 + r4 + j) * (uint32_t)W + (uint32_t)(tx * 64 + col);
+            const uint32_t q = ((uint32_t)(ty * 64 + r4 + j) << 16) | (uint32_t)(tx * 64 + col); // (row, column): launch_irv checks H < 2^14, W < 2^16
             if ((uint32_t)k < HW) list[k] = q | (f[j] == 2 ? IV_LATER : 0u); // the list holds HW entries: a counter that was not cleared can never write past it
             else atomicOr(a.diag, 1u); // (never on the timed path)
             ++k;
@@ -681,7 +685,6 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote_cm(IrvArgs a, in
     if (n_raw > H * W && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.diag, 2u);
     const int chl = max(1, min(IVC_CH, n >> 14)); // entries per trip (1080p, real content: 5; 4 to 16 measured alike, 16 slower)
     const int nchunks = (n + chl - 1) / chl, stride = gridDim.x * IV_WAVES;
-    const int HWi = H * W;
     const int half4 = (lane >> 5) * 4, lw = lane & 31;
     const uint32_t l2h = 2u * (uint32_t)lw, lane2 = 2u * lane;
 
@@ -718,7 +721,9 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote_cm(IrvArgs a, in
                     }
                 }
             };
-            if (cnt <= 8) steps(std::integral_constant<int, 2>()); // (64 is a multiple of 2 U: no wrap of the lane index)
+            // one trip (one load latency) for the few rows of an update; (64 is a multiple of 2 U: no wrap of the lane index)
+            if (cnt <= 4) steps(std::integral_constant<int, 2>());
+            else if (cnt <= 8) steps(std::integral_constant<int, 4>());
             else steps(std::integral_constant<int, IV_U>());
             return;
         }
@@ -761,8 +766,8 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote_cm(IrvArgs a, in
         float own_l = 0.f;
         if (lane < chl && i0 + lane < n) {
             e_l = list[i0 + lane];
-            const uint32_t q = e_l & ~(IV_ACCEPTED | IV_LATER);
-            if (q < (uint32_t)HWi) {
+            const uint32_t yx = e_l & ~(IV_ACCEPTED | IV_LATER), q = (yx >> 16) * (uint32_t)W + (yx & 0xffffu);
+            if ((yx >> 16) < (uint32_t)H && (yx & 0xffffu) < (uint32_t)W) {
                 cu_l = a.aU[v][q];
                 cd_l = a.aD[v][q];
                 own_l = disp[q];
@@ -773,21 +778,20 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote_cm(IrvArgs a, in
         for (int k = 0; k < chl && i0 + k < n; ++k) {
             const int i = i0 + k;
             const uint32_t entry = (uint32_t)__builtin_amdgcn_readlane((int)e_l, k);
-            if ((entry & ~(IV_ACCEPTED | IV_LATER)) >= (uint32_t)HWi) { // IV_DEAD, or not a pixel of this frame (stale memory behind a wrong counter)
+            const int gy = (int)((entry & ~(IV_ACCEPTED | IV_LATER)) >> 16), gx = (int)(entry & 0xffffu); // entries are (row << 16 | column)
+            if (gy >= H || gx >= W) { // IV_DEAD, or not a pixel of this frame (stale memory behind a wrong counter)
                 if (entry != IV_DEAD && lane == 0) atomicOr(a.diag, 4u);
                 continue;
             }
+            const int p = gy * W + gx;
             if ((entry & IV_LATER) && it == 0) continue; // S <= thresh_s in this iteration: rejected whatever the votes (the flag is ignored afterwards)
             if (entry & IV_ACCEPTED) { // accepted by the previous launch: bring this launch's write plane up to date
                 if (lane == 0) {
-                    const uint32_t q = entry & ~IV_ACCEPTED;
-                    code_nx[q] = code_pl[q];
+                    code_nx[p] = code_pl[p];
                     list[i] = IV_DEAD;
                 }
                 continue;
             }
-            const int p = (int)(entry & ~IV_LATER);
-            const int gy = p / W, gx = p - gy * W;
             int cu = __builtin_amdgcn_readlane(cu_l, k), cd = __builtin_amdgcn_readlane(cd_l, k);
             const float own = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, own_l), k));
             if (cu > usd) cu = usd;   // d_dr_irv.cu:179-180
@@ -798,7 +802,8 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote_cm(IrvArgs a, in
                 const int ty0 = (gy - cu) >> tile_sh, ty1 = (gy + cd) >> tile_sh;
                 const int nx = tx1 - tx0 + 1, nt = nx * (ty1 - ty0 + 1);
                 int d = nt > 64; // more tiles than lanes (cannot happen with launch_irv's tile size): do not prune
-                if (lane < nt) d = dirty[(ty0 + lane / nx) * tiles_x + tx0 + lane % nx];
+                const int lq = (lane * ((0x10000 + nx - 1) / nx)) >> 16; // lane / nx for lane < 64, nx <= 8 (the scalar unit divides once)
+                if (lane < nt) d = dirty[(ty0 + lq) * tiles_x + tx0 + (lane - lq * nx)];
                 if (__ballot(d != 0) == 0) continue; // same region contents as last time -> same vote -> rejected again
             }
             const int t0 = gy - cu, t1 = gy + cd; // rows t0 .. t1 inclusive (SURVEY A-Q17 iii)
@@ -849,7 +854,7 @@ __global__ __launch_bounds__(64 * IV_WAVES) void stm_k_irv_vote_cm(IrvArgs a, in
                     disp[p] = (float)max_d;
                     code_nx[p] = nc;
                     dirty_out[(gy >> tile_sh) * tiles_x + (gx >> tile_sh)] = 1; // same value from every writer
-                    list[i] = (uint32_t)p | IV_ACCEPTED;
+                    list[i] = (entry & ~IV_LATER) | IV_ACCEPTED;
                 }
             } else if (!paper_ratio && total > 0 && !((float)max(nb - 1, (int)own + zd) / (float)total > thresh_h)) {
                 // S only grows and the numerator never exceeds this bound (see stm_k_irv_rowcount): rejected now = rejected for good
@@ -911,17 +916,21 @@ void launch_irv(int nviews, float *const *disp, u8 *const *outl, const u8 *const
         return;
     }
     ProfScope p("irv");
-    STM_LAUNCH(stm_k_irv_clear, dim3((unsigned)cdiv((int)nwords, 256)), dim3(256), 0, stream(), counts, (int)nwords);
-    STM_CHECK_LAUNCH();
+    if (!prune) {
+        STM_LAUNCH(stm_k_irv_clear, dim3((unsigned)cdiv((int)nwords, 256)), dim3(256), 0, stream(), counts, (int)nwords);
+        STM_CHECK_LAUNCH();
+    }
     if (prune) {
-        STM_LAUNCH(stm_k_irv_rowcount, dim3(H, nviews), dim3(64 * IRC_W), (size_t)(W + 1) * 4, stream(), a, cnt[0], nviews == 2 ? cnt[1] : cnt[0], H, W);
+        STM_LAUNCH(stm_k_irv_rowcount, dim3(H, nviews), dim3(64 * IRC_W), (size_t)(W + 1) * 4, stream(), a, cnt[0], nviews == 2 ? cnt[1] : cnt[0], H, W,
+                   counts, (int)nwords);
         STM_CHECK_LAUNCH();
         STM_LAUNCH(stm_k_irv_colprefix, dim3(cdiv(W, 64), nviews), dim3(64 * ICP_SEG), 0, stream(), cnt[0], nviews == 2 ? cnt[1] : cnt[0], vp[0],
                    nviews == 2 ? vp[1] : vp[0], H, W);
         STM_CHECK_LAUNCH();
     }
     // round 4: the list column-major inside 64 x 64 tiles, a wave votes for runs of a column incrementally; 300: the raster list of round 3
-    const bool runs = (agg_variant() / 100) % 10 != 3;
+    // (also for frames too large for the (row, column) entries of the new list)
+    const bool runs = (agg_variant() / 100) % 10 != 3 && H < (1 << 14) && W < (1 << 16);
     if (runs) {
         const int t64x = cdiv(W, 64), t64y = cdiv(H, 64);
         STM_LAUNCH(stm_k_irv_compact_cm, dim3((unsigned)(t64x * t64y), nviews), dim3(IC_T), 0, stream(), a, (uint32_t)HW, zd, nb, H, W, usd, thresh_h,

@@ -761,12 +761,13 @@ def test_device_frame_with_hslo_ragged_width(gpu_ready, orc, variant):
     assert np.array_equal(out.cpu().numpy(), want["interlaced"])
 
 
-@pytest.mark.parametrize("variant", [0, 10, 20, 200, 1000, 2000, 10000, 1000000, 10000000, 100000000, 1000000000])
+@pytest.mark.parametrize("variant", [0, 10, 20, 200, 300, 1000, 2000, 10000, 1000000, 10000000, 100000000, 1000000000])
 @pytest.mark.parametrize("shape", [(40, 150, 130, 64, 34, 17), (64, 331, 64, 32, 20, 10), (151, 97, 20, 8, 36, 18)])
 def test_device_frame_agg_variants(gpu_ready, orc, variant, shape):
     """Every result-preserving kernel selection of stm_set_agg_variant (include/stm_hip.h) gives the oracle's frame: the row walks
     (0; D = 130 takes three chunk sets through them, with the per-pixel WTA carry in LDS), the block-per-segment horizontal kernels
-    (10; 20 = for D > 64 only; 1000 / 2000 = the cost-computing pass), unfused view synthesis (200), the vector-ALU aggregation
+    (10; 20 = for D > 64 only; 1000 / 2000 = the cost-computing pass), unfused view synthesis (200), region voting over the raster
+    list of round 3 instead of over column runs (300), the vector-ALU aggregation
     (10000), the separate cost kernel (1000000), the vertical passes on the LDS-ring kernel of round 3 instead of the register-ring
     kernel (10000000; the third shape has usd = 36, the longest arms the register-ring kernels take, and a height of 151 rows: a
     ragged last tile and three tiles of run-out), the last horizontal pass + WTA on the LDS row walk instead of the register-ring
