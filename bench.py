@@ -269,9 +269,11 @@ def main():
         # per view (read through the table); pq_hw = last pass + WTA: V in, 2 arm planes, disparity out.  The frame moves 8 V.
         # Vector-ALU kernels (--agg-variant 10000): as round 1.
         hslo = bool(args.stages & 0x100)
+        hsr = p.usd <= 36 and D <= 64 and args.agg_variant == 0 and not hslo  # the last pass + WTA runs stm_k_pq_hsr (stm_kernels_aggh.hip)
         fused_cost = "pq_cost" not in kern
         alg = {"pq_cost": 2 * V + 16 * HW, "pq_h": 2 * (V + 18 * HW) if fused_cost else 2 * (2 * V + 2 * HW),
-               "pq_vtab": 4 * HW + tab_bytes, "pq_v12": 2 * (2 * V + 2 * HW), "pq_hw": 2 * (V + 6 * HW),
+               "pq_vtab": 4 * HW + tab_bytes, "pq_v12": 2 * (2 * V + 2 * HW),
+               "pq_hw": 2 * (V + 6 * HW) + (2 * H * ((W + 15) // 16) * 256 if hsr else 0),  # (+ stm_k_pq_hsr's window table: 256 B per tile of 16 pixels)
                "agg_h": (2 * V + 2 * HW) if hslo else 2 * (V + 2 * HW + 16 * HW), "agg_v": 2 * V + 2 * HW,
                "agg_hw": 2 * (V + 2 * HW + 4 * HW), "cost_init": 2 * V + 4 * 4 * HW}
         # useful adds per launch = the reference's own count of float adds (one per window element, d_ca_cross_sum.cu:189-194,
@@ -299,7 +301,7 @@ def main():
         dom = max(agg_names, key=lambda k: kern[k]["total_ms"])
         stage_ms = sum(kern[k]["total_ms"] for k in per_kernel) / my_frames
         stage_bytes = sum(alg[k] * kern[k]["launches"] for k in per_kernel) / my_frames
-        roofline = {"bound": per_kernel[dom]["bound"], "kernel": {"pq_v12": "stm_k_pq_v12r" if p.usd <= 36 and args.agg_variant == 0 else "stm_k_pq_v12t", "pq_h": "stm_k_pq_hc", "pq_hw": "stm_k_pq_hs"}.get(dom, "stm_k_" + dom),
+        roofline = {"bound": per_kernel[dom]["bound"], "kernel": {"pq_v12": "stm_k_pq_v12r" if p.usd <= 36 and args.agg_variant == 0 else "stm_k_pq_v12t", "pq_h": "stm_k_pq_hc", "pq_hw": "stm_k_pq_hsr" if hsr else "stm_k_pq_hs"}.get(dom, "stm_k_" + dom),
                     "achieved": per_kernel[dom]["achieved"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": per_kernel[dom]["traffic"],
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg[dom],

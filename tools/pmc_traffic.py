@@ -24,6 +24,8 @@ def short(name):
     n = name.split("(")[0].replace("void ", "").replace("stm::", "")
     if "stm_k_pq_hc" in n:
         return "pq_h"                             # round 3: the cost-computing streaming pass
+    if "stm_k_pq_hsr" in n:
+        return "pq_hw"                            # round 4: the last pass + WTA with the window range in registers
     if "stm_k_pq_hs" in n or "stm_k_pq_h<" in n:
         args = n[n.index("<") + 1:n.index(">")].split(", ")
         return "pq_hw" if len(args) >= 2 and args[1] == "true" else "pq_h"   # <NW, WTA, ...>
