@@ -135,11 +135,13 @@ def test_ca_cross_rows_between_1024_and_2048(gpu_ready, orc, H, W, D):
                                               (130, 40, 80, 40, 60, 30), (16, 16, 16, 8, 3, 1), (18, 21, 33, 0, 9, 4),
                                               (40, 50, 8, 4, 150, 60), (300, 24, 12, 6, 110, 40), (24, 36, 5, 2, 1, 1),
                                               (1, 1, 1, 0, 3, 1), (2, 3, 2, 1, 5, 2), (3, 5, 1, 0, 34, 17), (1, 70, 4, 2, 9, 4),
-                                              (70, 1, 3, 1, 9, 4), (17, 4, 64, 63, 4, 2), (5, 260, 65, 0, 20, 10)])
+                                              (70, 1, 3, 1, 9, 4), (17, 4, 64, 63, 4, 2), (5, 260, 65, 0, 20, 10),
+                                              (12, 700, 32, 16, 36, 18), (9, 1003, 7, 3, 20, 10)])
 def test_matrix_pipe_aggregation_shapes(gpu_ready, orc, H, W, D, zd, usd, lsd):
     """The frame pipeline's aggregation kernels (stm_kernels_aggm.hip) on ragged shapes: W % 4 != 0 (partial pixel groups),
     D % 16 != 0 (padded chunks), D > 64 (several chunk sets), arms longer than the image, zd at the range edge, usd = 110 (the
-    longest arm whose two row rings fit the LDS), usd = 150 (falls back to the vector-ALU kernels), usd = 1."""
+    longest arm whose two row rings fit the LDS), usd = 150 (falls back to the vector-ALU kernels), usd = 1; the last two: rows of
+    44 and 63 tiles, which the register-ring horizontal kernel (stm_kernels_aggh.hip) splits over four and six waves, usd = 36."""
     from stm_amd import device_api as dev, synth
     sbs, _ = synth.sbs_frame(H, W, D, zd, seed=H * 1000 + W)
     p = dev.FrameParams(num_disp=D, zero_disp=zd, usd=usd, lsd=lsd)
