@@ -74,7 +74,8 @@ int         stm_prof_read(const char *kernel, float *total_ms);
  * computing the costs inside the first pass, 1000 / 2000 = the cost-computing pass as one block per segment (128- / 192-pixel
  * segments) instead of the row walk, 10 = the volume-reading horizontal passes as one block per segment instead of the row walk
  * (20: only for num_disp > 64), 200 = view synthesis and interlacing as two kernels, 300 = region voting over the raster-ordered outlier list of round 3
- * instead of over column runs, 10000000 = the vertical passes on the LDS-ring
+ * instead of over column runs, 400 = the two horizontal scanline-optimisation passes as two launches instead of one walk from both
+ * ends of a row, 10000000 = the vertical passes on the LDS-ring
  * kernel of round 3 instead of the register-ring kernel (stm_kernels_aggv.hip), 100000000 = the last horizontal pass + WTA on the
  * LDS row walk instead of the register-ring kernel (stm_kernels_aggh.hip), 1000000000 = that kernel's window table from its own
  * launch instead of from the cross-arm kernel.  Every accepted variant produces identical

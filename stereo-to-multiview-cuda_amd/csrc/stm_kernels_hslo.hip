@@ -23,6 +23,7 @@
 // D2 classes of a group with one unaligned dword load, the wave fetches the four D1 classes with another, and the pair
 // (P1, P2) of a step is one 8-byte LDS read from a 9-entry table at offset 24 class(D1) + 8 class(D2).
 #include "stm_common.h"
+#include <type_traits>
 
 namespace stm {
 
@@ -326,6 +327,178 @@ __global__ __launch_bounds__(64 * HH_WPB) void stm_k_hslo_h(HsloArgs a, int D, i
     }
 }
 
+// Both horizontal directions of a row in ONE walk (round 4, D <= 64): the walk of one direction is a chain of dependent
+// steps (a 6-stage DPP minimum, the step, one pixel after the other: 0.43 + 0.64 ms for two launches at two waves per SIMD),
+// so a wave walks its row from BOTH ends at once -- two independent recurrences whose instructions interleave.  Iteration v
+// takes group v left -> right and group G - 1 - v right -> left.  In the first half of the walk either side is the first
+// to visit its group and stores its path costs; in the second half it finds the other side's there and stores the sum.  The sum
+// C_lr + C_rl is one float add in either order, so the result is the one the two-launch form (and the oracle) produce.
+// A group's stored costs are written and read by the same lane of the same wave, in program order; they are requested PF
+// groups ahead only when the store is already behind (2 v >= G - 1 + PF), else at the step itself.
+__device__ __forceinline__ void wave_min2(float &a, float &b)
+{
+#define STM_MIN2_STAGE(ctrl)                                              \
+    "v_min_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"    \
+    "v_min_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t"    \
+    "s_nop 0\n\t"
+    asm volatile("s_nop 1\n\t" STM_MIN2_STAGE("row_shr:1") STM_MIN2_STAGE("row_shr:2") STM_MIN2_STAGE("row_shr:4") STM_MIN2_STAGE("row_shr:8")
+                     STM_MIN2_STAGE("row_bcast:15") STM_MIN2_STAGE("row_bcast:31") "s_nop 0"
+                 : "+v"(a), "+v"(b));
+#undef STM_MIN2_STAGE
+    a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+    b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
+}
+
+template <int DPL, int PF>
+__global__ __launch_bounds__(64) void stm_k_hslo_h2(HsloArgs a, int D, int zd, int H, int W, int G, int WU, int WP, int PAD, int dbg)
+{
+    __shared__ float2 ptab[9];
+    if (threadIdx.x < 9) ptab[threadIdx.x] = make_float2(a.p1[threadIdx.x], a.p2[threadIdx.x]);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x, view = blockIdx.y;
+    const int osign = a.osign[view];
+    const f4 *cp[DPL];
+    f4 *ap[DPL];
+    const u8 *c2f[DPL], *c2b[DPL];
+    int gs[DPL]; // float4 elements between consecutive groups (0 for an absent hypothesis: it keeps reading the +inf block)
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) {
+        const int d = lane + 64 * j;
+        const bool ok = d < D;
+        const size_t off = (((size_t)(d >> 4) * H + y) * G) * 16 + (d & 15);
+        cp[j] = ok ? a.cost[view] + off : a.inf;
+        ap[j] = ok ? a.acc[view] + off : a.inf;
+        gs[j] = ok ? 16 : 0;
+        c2f[j] = a.c2[view][0] + (size_t)y * WP + PAD + (ok ? osign * (d - zd) : 0);
+        c2b[j] = c2f[j] + 1;
+    }
+    const u8 *upf = a.u[view][0] + (size_t)y * WU, *upb = a.u[view][1] + (size_t)y * WU;
+
+    struct Row {
+        f4 c[DPL], s[DPL];
+        uint32_t c2[DPL], u;
+    };
+    auto load_row = [&](Row &r, int v, auto bwd_) { // v = iteration
+        constexpr bool BWD = decltype(bwd_)::value;
+        const int vv = min(v, G - 1), g = BWD ? G - 1 - vv : vv;
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            r.c[j] = nt_load4(cp[j] + (size_t)g * gs[j]);
+            if (2 * vv >= G - 1 + PF) r.s[j] = *(ap[j] + (size_t)g * gs[j]); // the other side's store is behind us
+            r.c2[j] = *(const u32_unaligned *)((BWD ? c2b[j] : c2f[j]) + 4 * g);
+        }
+        r.u = *(const uint32_t *)((BWD ? upb : upf) + 4 * g);
+    };
+
+    float prevF[DPL], prevB[DPL];
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) prevF[j] = prevB[j] = 0.f;
+    bool firstF = true, firstB = true; // the next valid pixel starts the line: Cr(p0, d) = C(p0, d)
+    auto process = [&](const Row &rf, const Row &rb, int v) {
+        const int gF = v, gB = G - 1 - v;
+        const bool second = 2 * v > G - 1, mid = 2 * v == G - 1;
+        const uint32_t uwF = __builtin_amdgcn_readfirstlane(rf.u), uwB = __builtin_amdgcn_readfirstlane(rb.u);
+        f4 sF[DPL], sB[DPL], oF[DPL], oB[DPL];
+        if (second) {
+#pragma unroll
+            for (int j = 0; j < DPL; ++j) {
+                if (2 * v >= G - 1 + PF) { sF[j] = rf.s[j]; sB[j] = rb.s[j]; }
+                else { sF[j] = *(ap[j] + (size_t)gF * gs[j]); sB[j] = *(ap[j] + (size_t)gB * gs[j]); }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            oF[j] = second ? sF[j] : rf.c[j];
+            oB[j] = second ? sB[j] : (mid ? (f4){0.f, 0.f, 0.f, 0.f} : rb.c[j]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int kF = kk, kB = 3 - kk, xF = 4 * gF + kF, xB = 4 * gB + kB;
+            const bool vF = xF < W, vB = xB < W; // false only in the last group
+            float ccF[DPL], ccB[DPL], curF[DPL], curB[DPL];
+#pragma unroll
+            for (int j = 0; j < DPL; ++j) { ccF[j] = rf.c[j][kF]; ccB[j] = rb.c[j][kB]; }
+            if (vF && vB && !firstF && !firstB && !STM_DBG(dbg, 1)) { // both recurrences, interleaved
+                const uint32_t ubF = (uwF >> (8 * kF)) & 0xffu, ubB = (uwB >> (8 * kB)) & 0xffu;
+                float P1F[DPL], P2F[DPL], P1B[DPL], P2B[DPL];
+#pragma unroll
+                for (int j = 0; j < DPL; ++j) {
+                    const float2 pf = penalties(ptab, rf.c2[j], kF, ubF), pb = penalties(ptab, rb.c2[j], kB, ubB);
+                    P1F[j] = pf.x; P2F[j] = pf.y; P1B[j] = pb.x; P2B[j] = pb.y;
+                }
+                float mF = lane_min<DPL>(prevF), mB = lane_min<DPL>(prevB);
+                wave_min2(mF, mB);
+                hslo_step<DPL>(prevF, ccF, P1F, P2F, mF, curF, lane);
+                hslo_step<DPL>(prevB, ccB, P1B, P2B, mB, curB, lane);
+            } else { // the ends of the line
+                if (vF) {
+                    if (firstF || STM_DBG(dbg, 1)) {
+#pragma unroll
+                        for (int j = 0; j < DPL; ++j) curF[j] = ccF[j];
+                        firstF = false;
+                    } else {
+                        const uint32_t ubF = (uwF >> (8 * kF)) & 0xffu;
+                        float P1[DPL], P2[DPL];
+#pragma unroll
+                        for (int j = 0; j < DPL; ++j) { const float2 pq = penalties(ptab, rf.c2[j], kF, ubF); P1[j] = pq.x; P2[j] = pq.y; }
+                        const float m = wave_min(lane_min<DPL>(prevF));
+                        hslo_step<DPL>(prevF, ccF, P1, P2, m, curF, lane);
+                    }
+                }
+                if (vB) {
+                    if (firstB || STM_DBG(dbg, 1)) {
+#pragma unroll
+                        for (int j = 0; j < DPL; ++j) curB[j] = ccB[j];
+                        firstB = false;
+                    } else {
+                        const uint32_t ubB = (uwB >> (8 * kB)) & 0xffu;
+                        float P1[DPL], P2[DPL];
+#pragma unroll
+                        for (int j = 0; j < DPL; ++j) { const float2 pq = penalties(ptab, rb.c2[j], kB, ubB); P1[j] = pq.x; P2[j] = pq.y; }
+                        const float m = wave_min(lane_min<DPL>(prevB));
+                        hslo_step<DPL>(prevB, ccB, P1, P2, m, curB, lane);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < DPL; ++j) {
+                if (vF) { prevF[j] = curF[j]; oF[j][kF] = second ? sF[j][kF] + curF[j] : curF[j]; }
+                if (vB) { prevB[j] = curB[j]; oB[j][kB] = second ? sB[j][kB] + curB[j] : curB[j]; }
+            }
+        }
+        if (STM_DBG(dbg, 2)) return;
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            if (mid) { // one group, both sides in this iteration: C_lr + C_rl (pixels past the row keep the cost, as in the two-launch form)
+                f4 o = oF[j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (4 * gF + k < W) o[k] = oF[j][k] + oB[j][k];
+                nt_store4(ap[j] + (size_t)gF * gs[j], o);
+            } else if (second) { // final values: non-temporal (plain ones slow the vertical pass that follows)
+                nt_store4(ap[j] + (size_t)gF * gs[j], oF[j]);
+                nt_store4(ap[j] + (size_t)gB * gs[j], oB[j]);
+            } else {
+                *(ap[j] + (size_t)gF * gs[j]) = oF[j];
+                *(ap[j] + (size_t)gB * gs[j]) = oB[j];
+            }
+        }
+    };
+
+    Row bf[PF], bb[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) { load_row(bf[i], i, std::false_type()); load_row(bb[i], i, std::true_type()); }
+    for (int v0 = 0; v0 < G; v0 += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            if (v0 + i < G) process(bf[i], bb[i], v0 + i);
+            load_row(bf[i], v0 + PF + i, std::false_type());
+            load_row(bb[i], v0 + PF + i, std::true_type());
+        }
+    }
+}
+
 // ------------------------------------------------------------------ vertical passes
 // grid (cdiv(G, 4), views); block = 4 waves, one group of four columns each (adjacent groups: 1 KB contiguous per row and
 // chunk).  BWD = false: top->bottom, acc += C_tb;  BWD = true: bottom->top, ((acc + C_bt) * 0.25) -> WTA -> disp.
@@ -466,15 +639,26 @@ template <int DPL, int PF>
 void hslo_passes(const HsloArgs &a, int nviews, int D, int zd, int H, int W, int G, int WU, int WP, int PAD)
 {
     const int dbg = timing_knobs(); // timing build only (stm_common.h): 1 = no recurrence, 2 = no stores
-    {
-        ProfScope p("hslo_lr");
-        STM_LAUNCH((stm_k_hslo_h<DPL, false, PF>), dim3(cdiv(H, HH_WPB), nviews), dim3(64 * HH_WPB), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD, dbg);
-        STM_CHECK_LAUNCH();
+    bool both = false;
+    if constexpr (DPL == 1) {
+        if ((agg_variant() / 100) % 10 != 4) { // round 4: both horizontal directions in one walk; 400: two launches
+            ProfScope p("hslo_lr");
+            STM_LAUNCH((stm_k_hslo_h2<DPL, (PF > 4 ? 4 : PF)>), dim3(H, nviews), dim3(64), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD, dbg);
+            STM_CHECK_LAUNCH();
+            both = true;
+        }
     }
-    {
-        ProfScope p("hslo_rl");
-        STM_LAUNCH((stm_k_hslo_h<DPL, true, PF>), dim3(cdiv(H, HH_WPB), nviews), dim3(64 * HH_WPB), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD, dbg);
-        STM_CHECK_LAUNCH();
+    if (!both) {
+        {
+            ProfScope p("hslo_lr");
+            STM_LAUNCH((stm_k_hslo_h<DPL, false, PF>), dim3(cdiv(H, HH_WPB), nviews), dim3(64 * HH_WPB), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD, dbg);
+            STM_CHECK_LAUNCH();
+        }
+        {
+            ProfScope p("hslo_rl");
+            STM_LAUNCH((stm_k_hslo_h<DPL, true, PF>), dim3(cdiv(H, HH_WPB), nviews), dim3(64 * HH_WPB), 0, stream(), a, D, zd, H, W, G, WU, WP, PAD, dbg);
+            STM_CHECK_LAUNCH();
+        }
     }
     {
         ProfScope p("hslo_tb");

@@ -813,19 +813,26 @@ def test_device_frame_very_large_disparity_range(gpu_ready, orc):
     assert np.array_equal(out.cpu().numpy(), want["interlaced"])
 
 
+@pytest.mark.parametrize("variant", [0, 400])
 @pytest.mark.parametrize("stages", [1, 3])
-def test_device_frame_pipeline_with_hslo(gpu_ready, orc, stages):
-    """BASELINE config 3 ordering: aggregation -> scanline optimisation -> WTA -> DCC/IRV/bilateral (stages | 0x100)."""
+def test_device_frame_pipeline_with_hslo(gpu_ready, orc, stages, variant):
+    """BASELINE config 3 ordering: aggregation -> scanline optimisation -> WTA -> DCC/IRV/bilateral (stages | 0x100).
+    Variant 0: both horizontal directions of a row in one walk from both ends (D <= 64); 400: one launch per direction."""
     import torch
+    import stm_amd
     from stm_amd import device_api as dev, synth
-    H, W, D, zd = 90, 200, 24, 12
+    H, W, D, zd = 90, 201, 24, 12
     sbs, _ = synth.sbs_frame(H, W, D, zd)
     p = dev.FrameParams(num_disp=D, zero_disp=zd, usd=17, lsd=8)
     dl = torch.zeros(H, W, dtype=torch.float32, device="cuda")
     dr = torch.zeros_like(dl)
     out = torch.zeros(H, W, 3, dtype=torch.uint8, device="cuda")
-    dev.d_adcensus_stm(torch.from_numpy(sbs).cuda(), dl, dr, out, p, stages=stages | 0x100)
-    torch.cuda.synchronize()
+    stm_amd.lib().stm_set_agg_variant(variant)
+    try:
+        dev.d_adcensus_stm(torch.from_numpy(sbs).cuda(), dl, dr, out, p, stages=stages | 0x100)
+        torch.cuda.synchronize()
+    finally:
+        stm_amd.lib().stm_set_agg_variant(0)
     want = orc.adcensus_stm(sbs, H, W, p.num_views, p.angle, D, zd, p.ad_coeff, p.census_coeff, p.ucd, p.lcd, p.usd,
                             p.lsd, p.thresh_s, p.thresh_h, stop_after_wta=(stages == 1), hslo=True)
     key = "wta" if stages == 1 else "disp"

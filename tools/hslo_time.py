@@ -16,7 +16,9 @@ for variant in [int(x) for x in sys.argv[1:]]:
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(20): dev.d_adcensus_stm(d_sbs, dl, dr, out, p, stages=259)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 20
-    print("variant", variant, "ms/frame %.3f fps %.1f" % (dt * 1e3, 1 / dt), flush=True)
+    import zlib
+    crc = zlib.crc32(dl.cpu().numpy().tobytes()) ^ zlib.crc32(dr.cpu().numpy().tobytes()) ^ zlib.crc32(out.cpu().numpy().tobytes())
+    print("variant", variant, "ms/frame %.3f fps %.1f  crc %08x" % (dt * 1e3, 1 / dt, crc), flush=True)
     dev.prof_reset(); dev.prof_enable(True)
     for _ in range(5): dev.d_adcensus_stm(d_sbs, dl, dr, out, p, stages=259)
     torch.cuda.synchronize()
