@@ -75,7 +75,8 @@ int         stm_prof_read(const char *kernel, float *total_ms);
  * segments) instead of the row walk, 10 = the volume-reading horizontal passes as one block per segment instead of the row walk
  * (20: only for num_disp > 64), 200 = view synthesis and interlacing as two kernels, 300 = region voting over the raster-ordered outlier list of round 3
  * instead of over column runs, 400 = the two horizontal scanline-optimisation passes as two launches instead of one walk from both
- * ends of a row, 10000000 = the vertical passes on the LDS-ring
+ * ends of a row, 500 (tests) = the per-stage filter_bilateral_1 through the frame pipeline's integer-map kernel (which checks each tile
+ * of its input and takes the general form where the map is not integer-valued inside the colour table), 10000000 = the vertical passes on the LDS-ring
  * kernel of round 3 instead of the register-ring kernel (stm_kernels_aggv.hip), 100000000 = the last horizontal pass + WTA on the
  * LDS row walk instead of the register-ring kernel (stm_kernels_aggh.hip), 1000000000 = that kernel's window table from its own
  * launch instead of from the cross-arm kernel.  Every accepted variant produces identical

@@ -208,6 +208,32 @@ def test_refinement_chain(api, orc, H, W, D, zd, usd, lsd):
         assert_float_stage(api.filter_bilateral_1(dl, r, sc, ss, D), orc.filter_bilateral_1(dl, r, sc, ss, D))
 
 
+def test_bilateral_integer_map_kernel_checks_its_promise(api, orc, stm):
+    """The frame pipeline's bilateral kernel takes the colour-LUT index from an integer copy of its tile (maps of whole numbers whose
+    differences stay inside the LUT: WTA / region-voting output).  It checks that promise tile by tile and falls back to the
+    general form, so ANY map gives the reference's result (d_filter_bilateral.cu:284-300): whole numbers inside the LUT (fast
+    form), differences >= D (clamped LUT index), fractions, huge values, and a map where only some tiles break the promise.
+    stm_set_agg_variant(500) routes the per-stage filter through that kernel."""
+    rng = np.random.RandomState(11)
+    H, W, D = 70, 150, 16
+    maps = {"inside": rng.randint(-7, 8, (H, W)).astype(np.float32),
+            "wide": rng.randint(-40, 41, (H, W)).astype(np.float32),
+            "fractions": (rng.random_sample((H, W)) * 12 - 6).astype(np.float32),
+            "huge": (rng.randint(-3, 4, (H, W)) * 3.0e6).astype(np.float32)}
+    mixed = maps["inside"].copy()
+    mixed[20:30, 60:90] += 0.25   # a few tiles with fractions
+    mixed[50:60, 10:20] *= 9.0    # a few tiles wider than the LUT
+    maps["mixed"] = mixed
+    stm.lib().stm_set_agg_variant(500)
+    try:
+        for name, m in maps.items():
+            got = api.filter_bilateral_1(m, 7, 5.0, 10.0, D)
+            want = orc.filter_bilateral_1(m, 7, 5.0, 10.0, D)
+            assert np.array_equal(got, want), name
+    finally:
+        stm.lib().stm_set_agg_variant(0)
+
+
 def test_gaussian_and_bleed(api, orc):
     rng = np.random.RandomState(4)
     m = (rng.random_sample((45, 70)) > 0.8).astype(np.float32)
