@@ -54,6 +54,35 @@ void fill_g1(float *h, int n, float s, float) { gaussian_kernel_1d(h, n, s); }
 const float *rho_table(float ad, float ce) { return dev_table(0, 0, ad, ce, 768 + 72, fill_rho); } // [0..765] ad, [768..832] census
 const float *gauss2d_table(int r, float s) { return dev_table(1, r, s, 0.f, (size_t)(2 * r + 1) * (2 * r + 1), fill_g2); }
 const float *gauss1d_table(int n, float s) { return dev_table(2, n, s, 0.f, (size_t)(n > 0 ? n : 1), fill_g1); }
+// The radius-7 bilateral filter of a map that holds ONE whole number c in a pixel's whole 15 x 15 neighbourhood: every tap has the
+// weight spatial x colour[0], and the pixel's result is the same sequence of float operations whatever the pixel
+// (d_filter_bilateral.cu:284-300: weight = spatial * colour, norm += weight, res += value * weight, res / norm) -- a function of c
+// alone.  Entry i = the result for c = i - zd (the values a disparity map of this frame can hold), computed here with the kernel's
+// own operations in the kernel's order (this file is compiled -ffp-contract=off like the kernels).
+void fill_bil1(float *h, int size, float sigma_spatial, float sigma_color)
+{
+    const int D = size >> 12, zd = size & 4095;
+    std::vector<float> g2(15 * 15), g1((size_t)(D > 0 ? D : 1));
+    gaussian_kernel_2d(g2.data(), 7, sigma_spatial);
+    gaussian_kernel_1d(g1.data(), D, sigma_color);
+    const float gc = g1[0];
+    for (int i = 0; i < D; ++i) {
+        const float c = (float)(i - zd);
+        volatile float norm = 0.0f, res = 0.0f;
+        for (int t = 0; t < 15 * 15; ++t) {
+            volatile float w = g2[t] * gc;
+            norm = norm + w;
+            volatile float cw = c * w;
+            res = res + cw;
+        }
+        h[i] = res / norm;
+    }
+}
+const float *bilateral_one_value_table(int D, int zd, float sigma_spatial, float sigma_color)
+{
+    if (D < 1 || D >= (1 << 19) || zd < 0 || zd >= 4096) return nullptr;
+    return dev_table(3, D * 4096 + zd, sigma_spatial, sigma_color, (size_t)D, fill_bil1);
+}
 
 void sync() { STM_CHECK(hipStreamSynchronize(stream())); }
 
@@ -745,7 +774,8 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
         launch_irv(2, dv, ov, u, d, l, r, thresh_s, thresh_h, H, W, D, zero_disp, usd, 5, true);
     }
     // the maps are this pipeline's own WTA / region-voting output: integer-valued, any two of them differ by at most D - 1
-    launch_bilateral2(wl, d_disp_l, wr, d_disp_r, gauss2d_table(7, 10.0f), gauss1d_table(D, 5.0f), 7, H, W, D, true); // :150-151  (7, 5, 10)
+    launch_bilateral2(wl, d_disp_l, wr, d_disp_r, gauss2d_table(7, 10.0f), gauss1d_table(D, 5.0f), 7, H, W, D, true, // :150-151  (7, 5, 10)
+                      bilateral_one_value_table(D, zero_disp, 10.0f, 5.0f), zero_disp);
 }
 
 // hit maps -> bleed -> masks -> N-2 views -> interlace (d_io.cu:160-205)

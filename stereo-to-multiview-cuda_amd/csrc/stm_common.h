@@ -167,7 +167,7 @@ void launch_bilateral(const float *in, float *out, const float *spatial, const f
 // integer_maps: both maps hold integer-valued disparities any two of which differ by less than D (the frame pipeline's own
 // WTA / region-voting output)
 void launch_bilateral2(const float *in_a, float *out_a, const float *in_b, float *out_b, const float *spatial, const float *color,
-                       int radius, int H, int W, int D, bool integer_maps = false);
+                       int radius, int H, int W, int D, bool integer_maps = false, const float *one_value = nullptr, int zd = 0);
 void launch_gaussian_max(const float *in, float *out, const float *spatial, int radius, float sigma, int H, int W,
                          bool invert_input);
 // DIBR + mux (stm_kernels_dibr.hip)
