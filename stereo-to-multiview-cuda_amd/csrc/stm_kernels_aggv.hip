@@ -59,7 +59,14 @@ template <int EXP>
 __global__ __launch_bounds__(64, 2) void stm_k_pq_v12r(PQViews pv, const uint32_t *__restrict__ wtab, int rec, int H, int G, int NC, int nviews)
 {
     // block (one wave) -> (view, group, chunk); the NC chunk waves of a strip read the same window records: consecutive blocks
-    const int c = blockIdx.x % NC, sidx = blockIdx.x / NC;
+    // Consecutive blocks go to different XCDs (8, each with its own L2), but the NC chunk waves of a strip read the same window
+    // records: the work items are dealt out so that a strip's chunks follow each other on ONE XCD
+    int wi = blockIdx.x;
+    {
+        const int per_xcd = gridDim.x >> 3;
+        if (wi < 8 * per_xcd) wi = (wi & 7) * per_xcd + (wi >> 3);
+    }
+    const int c = wi % NC, sidx = wi / NC;
     if (sidx >= G * nviews) return;
     const int g = sidx % G, view = sidx / G;
     const int l = threadIdx.x;
