@@ -717,7 +717,8 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
 
     al = carve_arms(HW);
     ar = carve_arms(HW);
-    uint32_t *htab = nullptr;
+    uint32_t *htab = nullptr, *vtab = nullptr;
+    int vrec = 0, vtop = -1;
     {
         const uint32_t *pk[2] = {pk_l, pk_r};
         u8 *u[2] = {al.up, ar.up}, *d[2] = {al.down, ar.down}, *l[2] = {al.left, ar.left}, *r[2] = {al.right, ar.right};
@@ -725,7 +726,9 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
         // the last aggregation pass's horizontal window table comes out of the same kernel (it has the arms in registers)
         const size_t hw_dw = matrix_pipe ? aggm_frame_htab_dwords(D, H, W, usd, hslo) : 0;
         htab = hw_dw ? Workspace::get<uint32_t>(hw_dw) : nullptr;
-        launch_cross_arms2(2, pk, u, d, l, r, ucd, lcd, usd, lsd, H, W, pre ? wide : nullptr, htab);
+        const size_t vw_dw = matrix_pipe && htab ? aggm_frame_vtab_dwords(H, W, usd, &vrec, &vtop) : 0; // (both tables or the horizontal one alone)
+        vtab = vw_dw ? Workspace::get<uint32_t>(vw_dw) : nullptr;
+        launch_cross_arms2(2, pk, u, d, l, r, ucd, lcd, usd, lsd, H, W, pre ? wide : nullptr, htab, vtab, vrec, vtop);
     }
     // with refinement the raw WTA maps live in scratch and the bilateral filter, the last step, writes the caller's buffers
     float *wl = refine ? Workspace::get<float>(HW) : d_disp_l, *wr = refine ? Workspace::get<float>(HW) : d_disp_r;
@@ -742,7 +745,7 @@ void frame_disparity(u8 *img_l, u8 *img_r, float *d_disp_l, float *d_disp_r, Arm
         const uint32_t *pk[2] = {pk_l, pk_r}, *cn[2] = {cen[0], cen[1]};
         const u8 *u[2] = {al.up, ar.up}, *d[2] = {al.down, ar.down}, *l[2] = {al.left, ar.left}, *r[2] = {al.right, ar.right};
         float *dv[2] = {wl, wr};
-        launch_aggm_frame(pk, cn, rho_table(ad_coeff, census_coeff), va, vb, u, d, l, r, dv, D, zero_disp, H, W, usd, hslo, htab);
+        launch_aggm_frame(pk, cn, rho_table(ad_coeff, census_coeff), va, vb, u, d, l, r, dv, D, zero_disp, H, W, usd, hslo, htab, vtab);
         if (hslo) launch_hslo_wta_pq(2, vb, va, hs_a, hs_b, hs_sign, dv, 15.0f, 1.0f, 3.0f, D, zero_disp, H, W, elem_sz);
     } else if (hslo) {
         core_agg(cl, sc, al, D, H, W, usd);

@@ -144,7 +144,8 @@ void launch_cross_arms(const uint32_t *packed, u8 *up, u8 *down, u8 *left, u8 *r
                        float ucd, float lcd, int usd, int lsd, int H, int W);
 void launch_cross_arms2(int nviews, const uint32_t *const *packed, u8 *const *up, u8 *const *down, u8 *const *left,
                         u8 *const *right, float ucd, float lcd, int usd, int lsd, int H, int W, const uint32_t *const *wide_ready = nullptr,
-                        uint32_t *htab = nullptr); // htab: also build stm_k_pq_hsr's horizontal window table (aggh_table_dwords(nviews, H, W))
+                        uint32_t *htab = nullptr, // htab: also build stm_k_pq_hsr's horizontal window table (aggh_table_dwords(nviews, H, W))
+                        uint32_t *vtab = nullptr, int vrec = 0, int vtop = -1); // + vtab: and stm_k_pq_v12r's vertical one (aggm_frame_vtab_dwords)
 void launch_agg_h(Vol in, Vol out, const u8 *armL, const u8 *armR, int D, int H, int W);
 void launch_agg_v(Vol in, Vol out, const u8 *armU, const u8 *armD, int D, int H, int W, int usd);
 void launch_agg_h2(Vol in_a, Vol out_a, const u8 *armL_a, const u8 *armR_a, Vol in_b, Vol out_b, const u8 *armL_b, const u8 *armR_b,
@@ -207,8 +208,9 @@ size_t pq_volume_floats(int D, int H, int W);
 bool aggm_supports(int usd, int H, int W);
 void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, const float *lut, float *const *vol_a, float *const *vol_b,
                        const u8 *const *armU, const u8 *const *armD, const u8 *const *armL, const u8 *const *armR, float *const *disp,
-                       int D, int zd, int H, int W, int usd, bool keep_volume = false, uint32_t *htab_ready = nullptr);
+                       int D, int zd, int H, int W, int usd, bool keep_volume = false, uint32_t *htab_ready = nullptr, uint32_t *vtab_ready = nullptr);
 size_t aggm_frame_htab_dwords(int D, int H, int W, int usd, bool keep_volume);
+size_t aggm_frame_vtab_dwords(int H, int W, int usd, int *rec, int *top); // the vertical table in the register-ring kernel's static layout, or 0
 // ca_cross / d_ca_cross of one volume in the caller's layout on the matrix-pipe kernels; `out` may be `in`.  Returns false, with
 // `out` untouched, when the volume holds an infinite, NaN or denormal element (one host read-back of a flag): the caller runs
 // the vector-ALU kernels instead.  aggm_stage_bytes: what it carves from the current Workspace scope.

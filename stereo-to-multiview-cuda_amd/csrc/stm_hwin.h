@@ -68,4 +68,51 @@ static __device__ __forceinline__ void hwin_build(uint32_t *__restrict__ tab, ui
         }
 }
 
+// ---- the vertical window table (stm_k_vwin_table, stm_kernels_aggm.hip; layout: DESIGN.md section 3) -- one record, one wave.
+// Lane l = (column b = l / 16 of the group, row i = l % 16 of the tile); s0 / nn = first row and length of the lane's window
+// [y - armU, y + armD) (nn = 0: no window).  ev: VT_EV (or, top >= 0: 96) 64-bit slots of LDS owned by this wave.
+// top >= 0: the static layout of stm_k_pq_v12r ([0] first quad of the sweep inside the tile's range, masks of range quad J at 8 + 8 J).
+__device__ __forceinline__ int hw_wave_min_i(int v)
+{
+    v = min(v, hr_row_ror<8>(v)); v = min(v, hr_row_ror<4>(v)); v = min(v, hr_row_ror<2>(v)); v = min(v, hr_row_ror<1>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int hw_wave_max_i(int v)
+{
+    v = max(v, hr_row_ror<8>(v)); v = max(v, hr_row_ror<4>(v)); v = max(v, hr_row_ror<2>(v)); v = max(v, hr_row_ror<1>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+static __device__ __forceinline__ void vwin_build(uint32_t *__restrict__ dst, unsigned long long *ev, int u, int top, int s0, int nn)
+{
+    const int l = threadIdx.x & 63;
+    const int lo = hw_wave_min_i(nn ? s0 : 0x7fffffff);
+    const int hi = hw_wave_max_i(nn ? s0 + nn : -0x7fffffff);
+    const int K0 = hi > lo ? (lo & ~3) : 0, n_it = hi > lo ? (hi - K0 + 3) >> 2 : 0;
+    const int q0 = top >= 0 && n_it ? (K0 - (16 * u - top)) >> 2 : 0;
+    if (l < 8) dst[l] = l == 0 ? (uint32_t)(top >= 0 ? q0 : K0) : l == 1 ? (uint32_t)n_it : 0u;
+    unsigned long long *mk = (unsigned long long *)(dst + 8) + 4 * q0;
+    const int steps = 4 * n_it;
+    for (int j = l; j <= steps; j += 64) ev[j] = 0ull;
+    __builtin_amdgcn_wave_barrier();
+    if (nn) { // the window [s0, s0 + nn) lies inside [K0, K0 + steps]
+        atomicXor(&ev[s0 - K0], 1ull << l);
+        atomicXor(&ev[s0 + nn - K0], 1ull << l);
+    }
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long carry = 0ull;
+    for (int base = 0; base < steps; base += 64) {
+        unsigned long long e = base + l < steps ? ev[base + l] : 0ull;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(e, o);
+            if (l >= o) e ^= t;
+        }
+        e ^= carry;
+        if (base + l < steps) mk[base + l] = e;
+        carry = __shfl(e, 63);
+    }
+}
+
 } // namespace stm

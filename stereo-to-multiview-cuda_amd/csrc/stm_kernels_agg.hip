@@ -59,16 +59,25 @@ __global__ __launch_bounds__(256) void stm_k_widen_px(const uint32_t *__restrict
 struct ArmsArgs {
     const uint32_t *img[2]; // wide pixels
     u8 *up[2], *down[2], *left[2], *right[2];
-    uint32_t *htab; // HTAB: the horizontal window table of stm_k_pq_hsr, records of view 0 then view 1 (stm_hwin.h)
+    uint32_t *htab; // MODE >= 1: the horizontal window table of stm_k_pq_hsr, records of view 0 then view 1 (stm_hwin.h)
+    uint32_t *vtab; // MODE 2: the vertical window table of stm_k_pq_v12r (static layout), `vrec` dwords per record, `vtop` = its range's reach
+    int vrec, vtop;
 };
 
-template <bool HTAB>
-__global__ __launch_bounds__(256) void stm_k_cross_arms(ArmsArgs a, uint32_t tg_far, uint32_t tg_near, int usd, int lsd, int H, int W)
+// MODE 0: the arms.  MODE 1: + the horizontal window table (a wave = 64 pixels of a row = four of its tiles, arms in registers).
+// MODE 2 (round 4; the review's item 1c): + the VERTICAL window table as well.  A block is 16 rows x 64 columns, wave w = row w of
+// the tile row; the arms leave through LDS, and after one barrier wave w builds the record of the block's w-th group of four columns
+// (vwin_build: lane = (column of the group, row of the tile)) -- stm_k_vwin_table's launch and its read of the arm planes are gone.
+template <int MODE>
+__global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void stm_k_cross_arms(ArmsArgs a, uint32_t tg_far, uint32_t tg_near, int usd, int lsd, int H, int W)
 {
+    constexpr bool HTAB = MODE >= 1;
     const int v = blockIdx.z;
-    const int xr = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (HTAB ? (xr & ~63) >= W : xr >= W) return; // HTAB: whole waves only (no block-wide barrier below)
-    const int x = min(xr, W - 1); // HTAB: a lane past the row stays for the table's cross-lane steps (it repeats the last pixel, stores nothing)
+    const int wv_ = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int xr = MODE == 2 ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * 256 + threadIdx.x;
+    const int yr = MODE == 2 ? blockIdx.y * 16 + wv_ : blockIdx.y;
+    if (MODE == 1 ? (xr & ~63) >= W : MODE == 0 ? xr >= W : false) return; // MODE 1: whole waves only (no block-wide barrier below); MODE 2: everybody stays for the barrier
+    const int x = min(xr, W - 1), y = min(yr, H - 1); // a lane past the row / a wave past the image repeats the last pixel / row and stores nothing
     const int p = y * W + x;
     const uint32_t *__restrict__ img = a.img[v];
     const uint32_t anchor = img[p];
@@ -133,16 +142,32 @@ __global__ __launch_bounds__(256) void stm_k_cross_arms(ArmsArgs a, uint32_t tg_
         }
     }
 #undef STM_ARM_LOADS
-    if (xr < W) {
+    const bool inside = xr < W && yr < H;
+    if (inside) {
         a.up[v][p] = (u8)arm[0];
         a.down[v][p] = (u8)arm[1];
         a.left[v][p] = (u8)arm[2];
         a.right[v][p] = (u8)arm[3];
     }
     if (HTAB) {
-        __shared__ uint32_t ev_all[4][4 * 96];
+        __shared__ uint32_t ev_all[MODE == 2 ? 16 : 4][4 * 96];
         const int nTx = (W + 15) >> 4;
-        hwin_build(a.htab + (size_t)v * H * nTx * HR_REC, ev_all[threadIdx.x >> 6], y, blockIdx.x * 256 + (threadIdx.x & ~63), arm[2], arm[3], W, nTx);
+        if (yr < H) // (wave-uniform)
+            hwin_build(a.htab + (size_t)v * H * nTx * HR_REC, ev_all[wv_], yr, xr & ~63, arm[2], arm[3], W, nTx);
+    }
+    if (MODE == 2) {
+        __shared__ u8 s_u[16][64], s_d[16][64];
+        __shared__ unsigned long long ev_v[16][96];
+        const int l = threadIdx.x & 63;
+        s_u[wv_][l] = inside ? (u8)arm[0] : (u8)0; // no window outside the image
+        s_d[wv_][l] = inside ? (u8)arm[1] : (u8)0;
+        __syncthreads();
+        const int G = (W + 3) >> 2, nT = (H + 15) >> 4, gg = blockIdx.x * 16 + wv_, u = blockIdx.y;
+        if (gg < G) { // (wave-uniform)
+            const int b = l >> 4, i = l & 15;
+            const int aU = s_u[i][4 * wv_ + b], aD = s_d[i][4 * wv_ + b];
+            vwin_build(a.vtab + ((size_t)(v * nT + u) * G + gg) * a.vrec, ev_v[wv_], u, a.vtop, blockIdx.y * 16 + i - aU, aU + aD);
+        }
     }
 }
 
@@ -160,7 +185,7 @@ static uint32_t wide_threshold(float t)
 // nviews = 1 or 2: both views of a frame share the launch.  packed[] = BGRX planes (launch_pack_bgrx).
 void launch_cross_arms2(int nviews, const uint32_t *const *packed, u8 *const *up, u8 *const *down, u8 *const *left,
                         u8 *const *right, float ucd, float lcd, int usd, int lsd, int H, int W, const uint32_t *const *wide_ready,
-                        uint32_t *htab)
+                        uint32_t *htab, uint32_t *vtab, int vrec, int vtop)
 {
     ArmsArgs a;
     const int n = H * W;
@@ -182,11 +207,17 @@ void launch_cross_arms2(int nviews, const uint32_t *const *packed, u8 *const *up
     }
     if (usd > 255) usd = 255; // arms are stored as u8 (reference T2)
     a.htab = htab;
-    if (htab && usd <= HR_TOP) // (longer arms than the table's range: the caller does not ask for it, aggh_supports)
-        STM_LAUNCH(stm_k_cross_arms<true>, dim3(cdiv(W, 256), H, nviews), dim3(256), 0, stream(), a, wide_threshold(ucd),
+    a.vtab = vtab;
+    a.vrec = vrec;
+    a.vtop = vtop;
+    if (htab && vtab && vtop >= 0 && usd <= HR_TOP && usd <= vtop) // both window tables (the caller asks for them when the register-ring kernels will run)
+        STM_LAUNCH(stm_k_cross_arms<2>, dim3(cdiv(W, 64), cdiv(H, 16), nviews), dim3(1024), 0, stream(), a, wide_threshold(ucd),
+                           wide_threshold(lcd), usd, lsd, H, W);
+    else if (htab && usd <= HR_TOP) // (longer arms than the table's range: the caller does not ask for it, aggh_supports)
+        STM_LAUNCH(stm_k_cross_arms<1>, dim3(cdiv(W, 256), H, nviews), dim3(256), 0, stream(), a, wide_threshold(ucd),
                            wide_threshold(lcd), usd, lsd, H, W);
     else
-        STM_LAUNCH(stm_k_cross_arms<false>, dim3(cdiv(W, 256), H, nviews), dim3(256), 0, stream(), a, wide_threshold(ucd),
+        STM_LAUNCH(stm_k_cross_arms<0>, dim3(cdiv(W, 256), H, nviews), dim3(256), 0, stream(), a, wide_threshold(ucd),
                            wide_threshold(lcd), usd, lsd, H, W);
     STM_CHECK_LAUNCH();
 }

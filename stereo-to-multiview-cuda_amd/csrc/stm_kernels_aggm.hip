@@ -28,7 +28,7 @@
 // hypothesis; vertical pass: the four columns of a float4 are the four blocks (the LDS rings hold a row as float
 // [4 columns][16 hypotheses], which lane 16 b + n reads linearly).  Every global access of a wave is 16 B per lane, 256 B
 // contiguous per 16 lanes, 1 KB contiguous per wave in the horizontal kernels.
-#include "stm_common.h"
+#include "stm_hwin.h"
 
 namespace stm {
 
@@ -847,33 +847,7 @@ __global__ __launch_bounds__(256) void stm_k_vwin_table(PQViews v, uint32_t *__r
         s0 = y - aU;
         nn = aU + aD;
     }
-    const int lo = wave_min_i(nn ? s0 : 0x7fffffff);
-    const int hi = wave_max_i(nn ? s0 + nn : -0x7fffffff);
-    const int K0 = hi > lo ? (lo & ~3) : 0, n_it = hi > lo ? (hi - K0 + 3) >> 2 : 0;
-    uint32_t *dst = tab + ((size_t)(view * nT + u) * G + g) * rec;
-    const int q0 = top >= 0 && n_it ? (K0 - (16 * u - top)) >> 2 : 0;
-    if (l < 8) dst[l] = l == 0 ? (uint32_t)(top >= 0 ? q0 : K0) : l == 1 ? (uint32_t)n_it : 0u;
-    unsigned long long *mk = (unsigned long long *)(dst + 8) + 4 * q0;
-    const int steps = 4 * n_it; // <= VT_EV - 1
-    for (int j = l; j <= steps; j += 64) ev[j] = 0ull;
-    __builtin_amdgcn_wave_barrier();
-    if (nn) { // the window [s0, s0 + nn) lies inside [K0, K0 + steps]
-        atomicXor(&ev[s0 - K0], 1ull << l);
-        atomicXor(&ev[s0 + nn - K0], 1ull << l);
-    }
-    __builtin_amdgcn_wave_barrier();
-    unsigned long long carry = 0ull;
-    for (int base = 0; base < steps; base += 64) {
-        unsigned long long e = base + l < steps ? ev[base + l] : 0ull;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned long long t = __shfl_up(e, o);
-            if (l >= o) e ^= t;
-        }
-        e ^= carry;
-        if (base + l < steps) mk[base + l] = e;
-        carry = __shfl(e, 63);
-    }
+    vwin_build(tab + ((size_t)(view * nT + u) * G + g) * rec, ev, u, top, s0, nn);
 }
 
 // Sweep of one tile: quads K0 / 4 .. K0 / 4 + n_it - 1 of a ring of RQ quad slots.  Two register sets (A, B) alternate: the
@@ -1142,7 +1116,7 @@ void launch_from_pq(const float *pq, Vol out, int D, int H, int W)
 //   from_costs: the first horizontal pass computes the initial costs itself (images -> vol_b), else it reads vol_a;
 //   then both vertical passes (vol_b -> vol_a); then the last horizontal pass, vol_a -> disparities (wta) or -> vol_b.
 static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const float *lut, int D, int zd, int H, int W, int usd,
-                       uint32_t *htab_ready = nullptr)
+                       uint32_t *htab_ready = nullptr, uint32_t *vtab_ready = nullptr)
 {
     const int G = (W + 3) / 4, NC = (D + 15) / 16;
     if (usd > 255) usd = 255;
@@ -1165,12 +1139,12 @@ static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const 
     const int rec = regs ? aggv_table_rec() : 8 + 8 * ((2 * usd + 21) / 4 + 2); // header + the longest sweep + one quad of read-ahead
     const int LAG = (UQ + TS - 1) / TS + 1;
     const int RQ1 = (TS + 2 * UQ) / 4, RQ2 = (TS * (LAG + 1) + UQ) / 4;
-    uint32_t *vtab = Workspace::get<uint32_t>((size_t)nviews * nT * G * rec);
+    uint32_t *vtab = regs && vtab_ready ? vtab_ready : Workspace::get<uint32_t>((size_t)nviews * nT * G * rec);
     // round 4: the row's window range in registers (stm_kernels_aggh.hip); 100000000: the LDS row walk stm_k_pq_hs
     const bool hregs = wta && aggh_supports(usd, D) && (agg_variant() / 100000000) % 10 != 1;
     uint32_t *htab = !hregs ? nullptr : htab_ready ? htab_ready : Workspace::get<uint32_t>(aggh_table_dwords(nviews, H, W));
     {
-        {
+        if (!(regs && vtab_ready)) {
             ProfScope p("pq_vtab");
             STM_LAUNCH(stm_k_vwin_table, dim3(cdiv(G, 4), nT, nviews), dim3(256), 0, stream(), v, vtab, rec, H, W, G, nT, regs ? aggv_table_top() : -1);
             STM_CHECK_LAUNCH();
@@ -1263,6 +1237,15 @@ static void aggm_chain(PQViews &v, int nviews, bool from_costs, bool wta, const 
 // keep_volume: the last pass writes the aggregated costs to vol_b instead of doing WTA (the HSLO stage follows; disp unused).
 // htab_ready: the horizontal window table of both views (aggm_frame_htab_dwords) already built by launch_cross_arms2, or nullptr.
 // aggm_frame_htab_dwords: its size when this frame's last pass will use it, else 0.
+size_t aggm_frame_vtab_dwords(int H, int W, int usd, int *rec, int *top)
+{
+    if (usd > 255) usd = 255;
+    const bool regs = aggv_supports(usd) && (agg_variant() / 10000000) % 10 != 1;
+    *rec = regs ? aggv_table_rec() : 0;
+    *top = regs ? aggv_table_top() : -1;
+    if (!regs || (agg_variant() / 1000000000) % 10 == 1) return 0; // 1000000000: the stand-alone table kernels
+    return (size_t)2 * ((H + 15) / 16) * ((W + 3) / 4) * *rec;
+}
 size_t aggm_frame_htab_dwords(int D, int H, int W, int usd, bool keep_volume)
 {
     if (usd > 255) usd = 255;
@@ -1271,14 +1254,14 @@ size_t aggm_frame_htab_dwords(int D, int H, int W, int usd, bool keep_volume)
 }
 void launch_aggm_frame(const uint32_t *const *pk, const uint32_t *const *cen, const float *lut, float *const *vol_a, float *const *vol_b,
                        const u8 *const *armU, const u8 *const *armD, const u8 *const *armL, const u8 *const *armR, float *const *disp,
-                       int D, int zd, int H, int W, int usd, bool keep_volume, uint32_t *htab_ready)
+                       int D, int zd, int H, int W, int usd, bool keep_volume, uint32_t *htab_ready, uint32_t *vtab_ready)
 {
     PQViews v;
     for (int i = 0; i < 2; ++i) {
         v.pk[i] = pk[i]; v.cen[i] = cen[i]; v.a[i] = vol_a[i]; v.b[i] = vol_b[i];
         v.armU[i] = armU[i]; v.armD[i] = armD[i]; v.armL[i] = armL[i]; v.armR[i] = armR[i]; v.disp[i] = disp[i];
     }
-    aggm_chain(v, 2, true, !keep_volume, lut, D, zd, H, W, usd, htab_ready);
+    aggm_chain(v, 2, true, !keep_volume, lut, D, zd, H, W, usd, htab_ready, vtab_ready);
 }
 
 // The per-stage aggregation (ca_cross / d_ca_cross, d_ca_cross.cu:255-270) of ONE volume in the caller's layout on the
