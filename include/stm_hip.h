@@ -78,8 +78,8 @@ int         stm_prof_read(const char *kernel, float *total_ms);
  * ends of a row, 500 (tests) = the per-stage filter_bilateral_1 through the frame pipeline's integer-map kernel (which checks each tile
  * of its input and takes the general form where the map is not integer-valued inside the colour table), 10000000 = the vertical passes on the LDS-ring
  * kernel of round 3 instead of the register-ring kernel (stm_kernels_aggv.hip), 100000000 = the last horizontal pass + WTA on the
- * LDS row walk instead of the register-ring kernel (stm_kernels_aggh.hip), 1000000000 = that kernel's window table from its own
- * launch instead of from the cross-arm kernel.  Every accepted variant produces identical
+ * LDS row walk instead of the register-ring kernel (stm_kernels_aggh.hip), 1000000000 = the window tables of the two register-ring
+ * kernels from their own launches instead of from the cross-arm kernel.  Every accepted variant produces identical
  * results (tests/test_gpu_parity.py::test_device_frame_agg_variants).  The
  * digit N00000 (timing experiments that skip parts of kernels) is ignored here: it exists only in libstm_hip_timing.so,
  * a separate build of the same sources with -DSTM_TIMING (csrc/Makefile, `make timing`). */

@@ -798,7 +798,7 @@ def test_device_frame_agg_variants(gpu_ready, orc, variant, shape):
     kernel (10000000; the third shape has usd = 36, the longest arms the register-ring kernels take, and a height of 151 rows: a
     ragged last tile and three tiles of run-out), the last horizontal pass + WTA on the LDS row walk instead of the register-ring
     kernel (100000000; the default takes the second and third shape: D = 64 and D = 20 < 64, rows of 21 and 7 tiles with a ragged
-    last one, split over two waves and one), its window table from the stand-alone kernel instead of stm_k_cross_arms (1000000000)."""
+    last one, split over two waves and one), the window tables of the register-ring kernels from the stand-alone kernels instead of stm_k_cross_arms (1000000000)."""
     import torch
     import stm_amd
     from stm_amd import device_api as dev, synth
